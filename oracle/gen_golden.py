@@ -1,0 +1,160 @@
+"""Generate tests/golden/*.npz by running the REAL reference on CPU  --  test infrastructure.
+
+Runs only in the build container (needs /root/reference; never on the GPU box).  It
+imports the reference's Network / Renderer / Encoder, loads a seeded state_dict, runs
+seeded inputs through them and records inputs, intermediates and outputs.  The fixtures
+are plain data (float/int arrays); no reference source is copied.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/
+
+Import recipe per SURVEY.md section 8(c): argv/cwd must be set before `src.config` is imported
+(argparse-at-import, CWD-relative paths); torch.cuda.synchronize is neutralised because
+volume_renderer.py:382,405 call it unconditionally (it does not touch arithmetic).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+
+sys.path.insert(0, HERE)
+import nerf_oracle as orc  # noqa: E402  (inputs/seeded weights come from the oracle helpers)
+
+
+def import_reference():
+    sys.argv = ["gen_golden", "--cfg_file", os.path.join(REF, "configs/nerf/lego.yaml")]
+    sys.path.insert(0, REF)
+    os.chdir(REF)
+    torch.cuda.synchronize = lambda *a, **k: None
+    from src.models.nerf.network import Network
+    from src.models.nerf.renderer.volume_renderer import Renderer
+    from src.models.encoding.freq import Encoder  # noqa: F401
+    return Network, Renderer
+
+
+def seeded_rays(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    o = torch.tensor([0.0, 0.0, 4.0]).expand(n, 3).contiguous()
+    d = torch.randn(n, 3, generator=g) * 0.2 + torch.tensor([0.0, 0.0, -1.0])
+    d = d / d.norm(dim=-1, keepdim=True)
+    return o, d.contiguous()
+
+
+def npz(name, **arrs):
+    conv = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()}
+    np.savez_compressed(os.path.join(OUT, name), **conv)
+    print("wrote", name, {k: v.shape for k, v in conv.items()})
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    Network, Renderer = import_reference()
+    sd = orc.synthetic_state_dict(seed=0)
+    net = Network()
+    assert list(net.state_dict().keys()) == orc.state_dict_keys(), "state_dict key drift"
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    ren = Renderer(net)
+    assert ren.perturb is False and ren.N_samples == 64 and ren.N_importance == 128
+    ren.device = torch.device("cpu")
+
+    # checkpoint in the reference's {"net": state_dict} layout (net_utils.py:374-375)
+    torch.save({"net": {k: v.clone() for k, v in sd.items()}, "epoch": 0}, os.path.join(OUT, "synthetic_ckpt.pth"))
+
+    with torch.no_grad():
+        # (1) positional encoding
+        g = torch.Generator().manual_seed(11)
+        x = (torch.rand(64, 3, generator=g) * 2 - 1) * 4.0
+        dirs = torch.randn(64, 3, generator=g); dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+        npz("pe.npz", x=x, dirs=dirs, pe_xyz=net.embed_fn(x), pe_dir=net.embeddirs_fn(dirs))
+
+        # (2) NeRF.forward per-layer activations, 128 points, both sub-models
+        pts = (torch.rand(128, 3, generator=g) * 2 - 1) * 3.0
+        vd = torch.randn(128, 3, generator=g); vd = vd / vd.norm(dim=-1, keepdim=True)
+        emb = torch.cat([net.embed_fn(pts), net.embeddirs_fn(vd)], -1)
+        rec = {"pts": pts, "viewdirs": vd, "emb": emb}
+        for tag, mdl in (("coarse", net.model), ("fine", net.model_fine)):
+            acts = {}
+            hooks = []
+            for i, l in enumerate(mdl.pts_linears):
+                hooks.append(l.register_forward_hook(lambda m, a, o, i=i: acts.__setitem__(f"h{i}", torch.relu(o))))
+            hooks.append(mdl.feature_linear.register_forward_hook(lambda m, a, o: acts.__setitem__("feature", o)))
+            hooks.append(mdl.views_linears[0].register_forward_hook(lambda m, a, o: acts.__setitem__("views", torch.relu(o))))
+            out = mdl(emb)
+            for h in hooks:
+                h.remove()
+            rec[f"{tag}_out"] = out
+            for k, v in acts.items():
+                rec[f"{tag}_{k}"] = v
+        npz("mlp_layers.npz", **rec)
+
+        # (3) Network.forward [8,64,3] -> [8,64,4], both models
+        o8, d8 = seeded_rays(8, 3)
+        t_c, pts_c = ren.stratified_sample_points_from_rays(o8, d8, N_samples=64, perturb=False)
+        vd8 = d8 / torch.norm(d8, dim=-1, keepdim=True)
+        npz("network_forward.npz", pts=pts_c, viewdirs=vd8,
+            raw_coarse=net.forward(pts_c, vd8, None, model=""),
+            raw_fine=net.forward(pts_c, vd8, None, model="fine"))
+
+        # (4)-(6) weights, fine sampling (incl. F7 tail), sorted depths
+        o, d = seeded_rays(256, 5)
+        t_c, pts_c = ren.stratified_sample_points_from_rays(o, d, N_samples=64, perturb=False)
+        vd = d / torch.norm(d, dim=-1, keepdim=True)
+        raw_c = net.forward(pts_c, vd, None, model="")
+        sigma_c = torch.relu(raw_c[..., 3])
+        T64, w64 = ren.weights_computation(sigma_c, t_c)
+        pts_f, t_f, vm = ren.fine_sample_points(sigma_c, o, d, t_c, 128, 64, 0.25)
+        assert vm is None
+        # re-derive the internals the reference does not return, with the reference's own ops
+        w = w64[:, 1:-1] + 1e-5
+        cdf = torch.cumsum(w / torch.sum(w, -1, keepdim=True), -1)
+        cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)
+        u = torch.linspace(0., 1., steps=128).expand(256, 128).contiguous()
+        inds = torch.searchsorted(cdf, u, right=True)
+        t_sorted, order = torch.sort(torch.cat([t_c, t_f], 1), dim=-1)
+        raw_f = net.forward(torch.gather(torch.cat([pts_c, pts_f], 1), 1, order[..., None].expand(-1, -1, 3)),
+                            vd, None, model="fine")
+        T192, w192 = ren.weights_computation(torch.relu(raw_f[..., 3]), t_sorted)
+        npz("sampling.npz", rays_o=o, rays_d=d, t_coarse=t_c, raw_coarse=raw_c, T64=T64, w64=w64,
+            cdf=cdf, inds=inds, t_fine=t_f, pts_fine=pts_f, t_sorted=t_sorted, raw_fine=raw_f,
+            T192=T192, w192=w192)
+
+        # (7) full render, N=256, N_importance in {0,128}; seeded-direction rays and pinhole rays
+        batch = {"rays_o": o[None], "rays_d": d[None]}
+        rgb128, dep128 = ren.render(batch)
+        ren.N_importance = 0
+        rgb0, dep0 = ren.render(batch)
+        ren.N_importance = 128
+        c2w = orc.camera_pose(30.0)
+        ids = torch.from_numpy(np.random.default_rng(0).choice(800 * 800, 256, replace=False))
+        po, pd = orc.pinhole_rays(800, 800, c2w, pixel_ids=ids)
+        prgb, pdep = ren.render({"rays_o": po[None], "rays_d": pd[None]})
+        npz("render.npz", rays_o=o, rays_d=d, rgb_128=rgb128, depth_128=dep128, rgb_0=rgb0, depth_0=dep0,
+            pin_rays_o=po, pin_rays_d=pd, pin_rgb=prgb, pin_depth=pdep, pin_c2w=c2w, pin_ids=ids)
+
+        # (7b) B>1 batch layout [2,96,3] -> [192,3]
+        o2, d2 = seeded_rays(192, 9)
+        r2, z2 = ren.render({"rays_o": o2.reshape(2, 96, 3), "rays_d": d2.reshape(2, 96, 3)})
+        npz("render_batched.npz", rays_o=o2.reshape(2, 96, 3), rays_d=d2.reshape(2, 96, 3), rgb=r2, depth=z2)
+
+    # (8) autograd fixture: MSE on fine RGB, grads of all 48 tensors for a 64-ray step
+    net.train()
+    o, d = seeded_rays(64, 21)
+    gt = torch.rand(64, 3, generator=torch.Generator().manual_seed(22))
+    rgb, dep = ren.render({"rays_o": o[None], "rays_d": d[None]})
+    loss = torch.nn.functional.mse_loss(rgb, gt)
+    net.zero_grad()
+    loss.backward()
+    grads = {"grad/" + k: p.grad for k, p in net.named_parameters()}
+    npz("autograd.npz", rays_o=o, rays_d=d, gt=gt, rgb=rgb, depth=dep, loss=loss, **grads)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,53 @@
+"""pytest configuration: the `gpu` marker and shared fixtures.
+
+`-m "not gpu"` runs here (no GPU): oracle vs golden vectors, host logic, C-ABI symbol checks,
+world_size-2 gloo sharding.  `-m gpu` runs on the MI355X box and calls the HIP path through the
+C-ABI.  Nothing here reads /root/reference (it does not exist on the GPU box).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(REPO, "tests", "golden")
+for p in (REPO, os.path.join(REPO, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name)) as z:
+        return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import nerf_oracle
+    return nerf_oracle
+
+
+@pytest.fixture(scope="session")
+def synthetic_sd(oracle):
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    return oracle.synthetic_state_dict(seed=0)
