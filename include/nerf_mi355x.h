@@ -1,0 +1,106 @@
+/* nerf_mi355x.h -- C ABI of libnerf_mi355x.so: the NeRF volume-rendering hot path on MI355X (gfx950).
+ *
+ * The reference (rkin100g/Nerf-Replication) is pure Python on PyTorch ATen ops: there is no native
+ * interface on this path to mirror.  The entry points below are therefore
+ * what a reference-side binding (ctypes) would call from inside the reference's
+ * own plugin surface:
+ *     src/models/nerf/renderer/volume_renderer.py:290-432   Renderer.render
+ *     src/models/nerf/network.py:199-258                    Network.forward
+ * Each function cites the reference lines whose arithmetic it replaces.
+ *
+ * Conventions: every pointer is a DEVICE pointer to contiguous row-major fp32 unless stated
+ * otherwise; inputs are borrowed, outputs are caller-allocated; `stream` is a hipStream_t (NULL =
+ * default stream); calls only enqueue work (no host sync, graph-capturable); the return value is 0
+ * on success or a negative nerf_status, never an exception; nerf_last_error() gives the message of
+ * the calling thread's last failure.  n_rays == 0 is a successful no-op everywhere.
+ */
+#ifndef NERF_MI355X_H
+#define NERF_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERF_ABI_VERSION 1
+
+enum nerf_status {
+  NERF_OK = 0,
+  NERF_ERR_INVALID_ARG = -1,   /* null pointer, negative size, unsupported sample counts */
+  NERF_ERR_WORKSPACE = -2,     /* workspace too small */
+  NERF_ERR_HIP = -3,           /* a HIP runtime call or kernel launch failed */
+  NERF_ERR_UNSUPPORTED = -4    /* precision / mode not built */
+};
+
+enum nerf_precision {
+  NERF_PREC_F32 = 0            /* exact fp32: v_mfma_f32_32x32x2_f32 (the parity path) */
+};
+
+/* Renderer constants the reference effectively hard-codes (volume_renderer.py:14-24). */
+#define NERF_N_SAMPLES 64
+#define NERF_N_IMPORTANCE 128
+
+int32_t nerf_abi_version(void);
+const char* nerf_last_error(void);
+
+/* Number of floats of one packed sub-model (coarse or fine). */
+int64_t nerf_packed_model_floats(void);
+
+/* Permute the 24 parameter tensors of one NeRF sub-model into the kernel's weight stream
+ * (csrc/nerf_layout.h).  `params` is a HOST array of 24 DEVICE pointers in the reference's
+ * state_dict order (network.py:22-47): pts_linears.0..7 {weight,bias}, views_linears.0,
+ * feature_linear, alpha_linear, rgb_linear; weights are nn.Linear [out,in] row-major.
+ * Runs on the device; call again whenever the parameters change (e.g. after an optimizer step). */
+int32_t nerf_pack_model(const float* const params[24], float* packed, void* stream);
+
+/* Positional encoding alone: x [n,3] -> out [n, 3+6*n_freqs] in the reference's channel order.
+ * Replaces freq.py:31-32 (Encoder.embed); n_freqs is 10 (xyz) or 4 (view dir). Uses the same
+ * device sincos as the fused MLP; exposed for parity tests. */
+int32_t nerf_positional_encoding(const float* x, int64_t n, int32_t n_freqs, float* out, void* stream);
+
+/* Network.forward(inputs[n,s,3], viewdirs[n,3], valid_mask=None, model) -> raw [n,s,4] = (r,g,b,sigma)
+ * pre-activation.  Replaces network.py:216-256: PE of points and directions, the batchify(512) loop
+ * over NeRF.forward (network.py:49-74), and the reshape.  `packed` selects coarse or fine model. */
+int32_t nerf_mlp_forward(const float* pts, const float* viewdirs, int64_t n_rays, int32_t n_samples,
+                         const float* packed, float* raw, int32_t precision, void* stream);
+
+/* Same network on points generated on the fly: pts = rays_o + rays_d * t (volume_renderer.py:63,
+ * :267), viewdirs = rays_d / ||rays_d|| (:314).  t of (ray i, sample s) is
+ * tvals[i*t_ray_stride + s]; t_ray_stride = 0 shares one table (the deterministic coarse linspace). */
+int32_t nerf_mlp_forward_rays(const float* rays_o, const float* rays_d, const float* tvals,
+                              int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
+                              const float* packed, float* raw, int32_t precision, void* stream);
+
+/* Hierarchical sampling + merge.  raw_coarse [n,64,4] (sigma = channel 3, pre-ReLU), t_coarse [64],
+ * u [128] -> t_sorted [n,192] (ascending union of coarse and fine depths), optional t_fine [n,128].
+ * Replaces ReLU of the coarse density (volume_renderer.py:335-338), weights_computation (:67-96),
+ * fine_sample_points' deterministic branch (:126-154, :247-264) incl. its index clamp to 61, and the
+ * cat + torch.sort of depths (:349-353); the sorted POINTS (:354-356) are regenerated as o + d*t. */
+int32_t nerf_sample_fine(const float* raw_coarse, const float* t_coarse, const float* u,
+                         int64_t n_rays, float* t_sorted, float* t_fine, void* stream);
+
+/* Final activations + alpha compositing.  raw [n,S,4], t per (ray,sample) as above ->
+ * rgb [n,3], depth [n], optional weights [n,S].  Replaces volume_renderer.py:414-432:
+ * sigmoid(rgb), relu(sigma), weights_computation, the two sums and the white background. */
+int32_t nerf_composite(const float* raw, const float* tvals, int64_t t_ray_stride, int64_t n_rays,
+                       int32_t n_samples, int32_t white_bkgd, float* rgb, float* depth,
+                       float* weights, void* stream);
+
+/* Bytes of scratch nerf_render_forward needs for n_rays rays. */
+int64_t nerf_render_workspace_bytes(int64_t n_rays, int32_t n_importance);
+
+/* Renderer.render for already-flattened rays [n,3]: coarse pass, hierarchical sampling, fine pass,
+ * compositing (volume_renderer.py:306-432).  n_importance is 0 (coarse only) or 128.  t_coarse [64]
+ * and u [128] are the host-built torch.linspace tables (bit-sensitive).
+ * Outputs rgb [n,3], depth [n]. */
+int32_t nerf_render_forward(const float* rays_o, const float* rays_d, int64_t n_rays,
+                            const float* packed_coarse, const float* packed_fine,
+                            const float* t_coarse, const float* u, int32_t n_importance,
+                            int32_t white_bkgd, int32_t precision, void* workspace,
+                            int64_t workspace_bytes, float* rgb, float* depth, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_MI355X_H */

@@ -1,0 +1,361 @@
+// libnerf_mi355x.so -- HIP kernels (gfx950 only) and the C ABI of include/nerf_mi355x.h.
+// Build: hipcc -O3 --offload-arch=gfx950 -shared -fPIC (see csrc/Makefile).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/nerf_mi355x.h"
+#include "nerf_layout.h"
+#include "nerf_mlp_f32.hip.inc"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* what) {
+  snprintf(g_err, sizeof(g_err), fmt, what);
+  return code;
+}
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return NERF_ERR_HIP;
+  }
+  return NERF_OK;
+}
+
+// ------------------------------------------------------------------------------------ pack
+struct PackArgs {
+  const float* p[nerf::P_COUNT];
+  float* out;
+};
+
+__device__ __forceinline__ float pack_weight_elem(const PackArgs& a, long long rel, int ntiles,
+                                                  int which /*0 L0,1 hidden,2 L5a,3 L5b,4 feat,5 views*/,
+                                                  int layer) {
+  using namespace nerf;
+  const int q = (int)(rel & 3);
+  const int lane = (int)((rel >> 2) & 63);
+  const long long blk = rel >> 8;                 // g*NT + j
+  const int j = (int)(blk % ntiles);
+  const int g = (int)(blk / ntiles);
+  const int s = 4 * g + q, t = s >> 4, r = s & 15, h = lane >> 5;
+  const int out = 32 * j + (lane & 31);
+  switch (which) {
+    case 0: { const int c = pe_xyz_feat(s, h); return c < 0 ? 0.f : a.p[P_W0][out * 63 + c]; }
+    case 1: return a.p[2 * layer][out * 256 + act_feat(t, r, h)];
+    case 2: { const int c = pe_xyz_feat(s, h); return c < 0 ? 0.f : a.p[10][out * 319 + c]; }
+    case 3: return a.p[10][out * 319 + 63 + act_feat(t, r, h)];
+    case 4: return a.p[P_WF][out * 256 + act_feat(t, r, h)];
+    default: {
+      if (t < 8) return a.p[P_WV][out * 283 + act_feat(t, r, h)];
+      const int c = pe_dir_feat(r, h);
+      return c < 0 ? 0.f : a.p[P_WV][out * 283 + 256 + c];
+    }
+  }
+}
+
+__global__ void nerf_pack_kernel(PackArgs a) {
+  using namespace nerf;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= kPackedFloats) return;
+  constexpr long long WS = wsize(128, 8);
+  float v;
+  if (i < kOffL1) v = pack_weight_elem(a, i - kOffL0, 8, 0, 0);
+  else if (i < kOffL5a) { const long long rel = i - kOffL1; v = pack_weight_elem(a, rel % WS, 8, 1, 1 + (int)(rel / WS)); }
+  else if (i < kOffL5b) v = pack_weight_elem(a, i - kOffL5a, 8, 2, 5);
+  else if (i < kOffL6) v = pack_weight_elem(a, i - kOffL5b, 8, 3, 5);
+  else if (i < kOffFeat) { const long long rel = i - kOffL6; v = pack_weight_elem(a, rel % WS, 8, 1, 6 + (int)(rel / WS)); }
+  else if (i < kOffViews) v = pack_weight_elem(a, i - kOffFeat, 8, 4, 0);
+  else if (i < kOffBias) v = pack_weight_elem(a, i - kOffViews, 4, 5, 0);
+  else if (i < kOffBiasViews) {          // [layer 0..8][h][j*16 + r]
+    const int rel = (int)(i - kOffBias), layer = rel >> 8, h = (rel >> 7) & 1, slot = rel & 127;
+    const float* b = layer < 8 ? a.p[2 * layer + 1] : a.p[P_BF];
+    v = b[act_feat(slot >> 4, slot & 15, h)];
+  } else if (i < kOffWAlpha) {           // [h][j*16 + r], j < 4
+    const int rel = (int)(i - kOffBiasViews), h = rel >> 6, slot = rel & 63;
+    v = a.p[P_BV][act_feat(slot >> 4, slot & 15, h)];
+  } else if (i < kOffWRgb) {             // [h][t*16 + r]
+    const int rel = (int)(i - kOffWAlpha), h = rel >> 7, slot = rel & 127;
+    v = a.p[P_WA][act_feat(slot >> 4, slot & 15, h)];
+  } else if (i < kOffHeadBias) {         // [c][h][t*16 + r], t < 4
+    const int rel = (int)(i - kOffWRgb), c = rel >> 7, h = (rel >> 6) & 1, slot = rel & 63;
+    v = a.p[P_WR][c * 128 + act_feat(slot >> 4, slot & 15, h)];
+  } else {
+    const int rel = (int)(i - kOffHeadBias);
+    v = rel < 3 ? a.p[P_BR][rel] : a.p[P_BA][0];
+  }
+  a.out[i] = v;
+}
+
+// ------------------------------------------------------------------------------------ PE (test entry)
+__global__ void nerf_pe_kernel(const float* __restrict__ x, long long n, int n_freqs, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int ch = 3 + 6 * n_freqs;
+  if (i >= n * 3) return;
+  const long long p = i / 3;
+  const int c = (int)(i - p * 3);
+  const float v = x[i];
+  out[p * ch + c] = v;
+  for (int k = 0; k < n_freqs; ++k) {
+    float sv, cv;
+    sincosf(v * (float)(1 << k), &sv, &cv);
+    out[p * ch + 3 + 6 * k + c] = sv;
+    out[p * ch + 3 + 6 * k + 3 + c] = cv;
+  }
+}
+
+// ------------------------------------------------------------------------------------ fine sampling
+// One thread per ray, sequential scans in the reference's CPU order (cumprod / cumsum are
+// sequential in torch CPU too); per-thread columns of cdf[63] and t_fine[128] live in LDS
+// (lds[k*64 + tid]: conflict-free).  < 1 % of a frame's time; HBM traffic 1 KiB in, 768 B out per ray.
+constexpr int kSampleThreads = 64;
+
+__device__ __forceinline__ float alpha_of(float sigma, float delta) {
+  return __fsub_rn(1.0f, expf(__fmul_rn(-sigma, delta)));       // 1 - exp(-sigma*delta)
+}
+
+__global__ __launch_bounds__(kSampleThreads)
+void nerf_sample_fine_kernel(const float* __restrict__ raw_c, const float* __restrict__ t_coarse,
+                             const float* __restrict__ u_tab, long long n_rays,
+                             float* __restrict__ t_sorted, float* __restrict__ t_fine_out) {
+  constexpr int S = NERF_N_SAMPLES, F = NERF_N_IMPORTANCE, NB = S - 1;   // 63 cdf entries / bins
+  __shared__ float s_tc[S];
+  __shared__ float s_u[F];
+  __shared__ float s_cdf[NB * kSampleThreads];
+  __shared__ float s_tf[F * kSampleThreads];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < S; i += kSampleThreads) s_tc[i] = t_coarse[i];
+  for (int i = tid; i < F; i += kSampleThreads) s_u[i] = u_tab[i];
+  __syncthreads();
+  const long long ray = (long long)blockIdx.x * kSampleThreads + tid;
+  if (ray >= n_rays) return;
+  const float* sig = raw_c + ray * (S * 4) + 3;
+  float* cdf = s_cdf + tid;     // stride kSampleThreads
+  float* tf = s_tf + tid;
+
+  // weights of the coarse pass (volume_renderer.py:67-96), inner 62 + eps, running sum
+  float T = 1.0f, wsum = 0.0f;
+  for (int i = 0; i < S; ++i) {
+    const float sigma = fmaxf(sig[i * 4], 0.0f);
+    const float delta = (i < S - 1) ? __fsub_rn(s_tc[i + 1], s_tc[i]) : 1e10f;
+    const float alpha = alpha_of(sigma, delta);
+    const float w = __fmul_rn(T, alpha);
+    if (i >= 1 && i <= S - 2) {
+      const float we = __fadd_rn(w, 1e-5f);
+      cdf[(i - 1) * kSampleThreads] = we;           // stash w+eps in cdf slots 0..61
+      wsum = __fadd_rn(wsum, we);
+    }
+    T = __fmul_rn(T, fminf(fmaxf(__fsub_rn(1.0f, alpha), 1e-10f), 1.0f));
+  }
+  // cdf = [0, cumsum(pdf)]  (63 entries)
+  {
+    float run = 0.0f, prev = cdf[0];
+    cdf[0] = 0.0f;
+    for (int m = 1; m < NB; ++m) {
+      run = __fadd_rn(run, __fdiv_rn(prev, wsum));
+      prev = cdf[m * kSampleThreads];
+      cdf[m * kSampleThreads] = run;
+    }
+  }
+  // inverse CDF at the fixed u table; u ascending -> the searchsorted(right=True) index only grows
+  int ind = 0;
+  for (int k = 0; k < F; ++k) {
+    const float u = s_u[k];
+    while (ind < NB && cdf[ind * kSampleThreads] <= u) ++ind;
+    const int below = min(max(ind - 1, 0), S - 3);
+    const int above = min(ind, S - 3);                 // clamp to 61: tail collapse
+    const float cb = cdf[below * kSampleThreads], ca = cdf[above * kSampleThreads];
+    const float bb = __fmul_rn(0.5f, __fadd_rn(s_tc[below + 1], s_tc[below]));
+    const float ba = __fmul_rn(0.5f, __fadd_rn(s_tc[above + 1], s_tc[above]));
+    float denom = __fsub_rn(ca, cb);
+    if (denom < 1e-5f) denom = 1.0f;
+    const float frac = __fdiv_rn(__fsub_rn(u, cb), denom);
+    float v = __fadd_rn(bb, __fmul_rn(frac, __fsub_rn(ba, bb)));
+    if (t_fine_out) t_fine_out[ray * F + k] = v;
+    // keep tf sorted even if rounding ever produced a 1-ulp inversion (torch.sort would fix it too)
+    int j = k;
+    while (j > 0 && tf[(j - 1) * kSampleThreads] > v) { tf[j * kSampleThreads] = tf[(j - 1) * kSampleThreads]; --j; }
+    tf[j * kSampleThreads] = v;
+  }
+  // two-way merge of the sorted coarse table and the sorted fine depths (= cat + torch.sort)
+  float* out = t_sorted + ray * (S + F);
+  int ic = 0, jf = 0;
+  float vc = s_tc[0], vf = tf[0];
+  for (int k = 0; k < S + F; ++k) {
+    const bool take_c = (jf >= F) || (ic < S && vc <= vf);
+    if (take_c) { out[k] = vc; ++ic; vc = ic < S ? s_tc[ic] : 0.0f; }
+    else { out[k] = vf; ++jf; vf = jf < F ? tf[jf * kSampleThreads] : 0.0f; }
+  }
+}
+
+// ------------------------------------------------------------------------------------ compositing
+__global__ __launch_bounds__(256)
+void nerf_composite_kernel(const float* __restrict__ raw, const float* __restrict__ tvals,
+                           long long t_ray_stride, long long n_rays, int S, int white_bkgd,
+                           float* __restrict__ rgb_out, float* __restrict__ depth_out,
+                           float* __restrict__ weights_out) {
+  const long long ray = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= n_rays) return;
+  const f32x4* r4 = reinterpret_cast<const f32x4*>(raw) + ray * S;
+  const float* t = tvals + ray * t_ray_stride;
+  float T = 1.0f, acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_w = 0.f;
+  float t_cur = t[0];
+  for (int k = 0; k < S; ++k) {
+    const f32x4 v = r4[k];
+    const float t_next = (k < S - 1) ? t[k + 1] : 0.0f;
+    const float delta = (k < S - 1) ? __fsub_rn(t_next, t_cur) : 1e10f;
+    const float alpha = alpha_of(fmaxf(v.w, 0.0f), delta);
+    const float w = __fmul_rn(T, alpha);
+    T = __fmul_rn(T, fminf(fmaxf(__fsub_rn(1.0f, alpha), 1e-10f), 1.0f));
+    const float cr = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v.x)));     // sigmoid
+    const float cg = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v.y)));
+    const float cb = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v.z)));
+    acc_r = __fadd_rn(acc_r, __fmul_rn(w, cr));
+    acc_g = __fadd_rn(acc_g, __fmul_rn(w, cg));
+    acc_b = __fadd_rn(acc_b, __fmul_rn(w, cb));
+    acc_d = __fadd_rn(acc_d, __fmul_rn(w, t_cur));
+    acc_w = __fadd_rn(acc_w, w);
+    if (weights_out) weights_out[ray * S + k] = w;
+    t_cur = t_next;
+  }
+  if (white_bkgd) {
+    const float bg = __fsub_rn(1.0f, acc_w);
+    acc_r = __fadd_rn(acc_r, bg); acc_g = __fadd_rn(acc_g, bg); acc_b = __fadd_rn(acc_b, bg);
+  }
+  rgb_out[ray * 3 + 0] = acc_r; rgb_out[ray * 3 + 1] = acc_g; rgb_out[ray * 3 + 2] = acc_b;
+  depth_out[ray] = acc_d;
+}
+
+// ------------------------------------------------------------------------------------ launch helpers
+int launch_mlp(const MlpArgs& a, bool ray_mode, int precision, hipStream_t st) {
+  if (precision != NERF_PREC_F32) return fail(NERF_ERR_UNSUPPORTED, "%s", "precision not built");
+  if (a.n_points <= 0) return NERF_OK;
+  const long long tiles = (a.n_points + nerf::kTilePts - 1) / nerf::kTilePts;
+  const long long blocks = (tiles + 3) / 4;
+  if (blocks > 0x7fffffffLL) return fail(NERF_ERR_INVALID_ARG, "%s", "too many points for one launch");
+  if (ray_mode) hipLaunchKernelGGL(nerf_mlp_f32_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(nerf_mlp_f32_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  return check_launch("nerf_mlp_f32_kernel");
+}
+
+inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+}  // namespace
+
+// ===================================================================================== C ABI
+extern "C" {
+
+int32_t nerf_abi_version(void) { return NERF_ABI_VERSION; }
+const char* nerf_last_error(void) { return g_err; }
+int64_t nerf_packed_model_floats(void) { return nerf::kPackedFloats; }
+
+int32_t nerf_pack_model(const float* const params[24], float* packed, void* stream) {
+  if (!params || !packed) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_pack_model: null argument");
+  PackArgs a;
+  for (int i = 0; i < nerf::P_COUNT; ++i) {
+    if (!params[i]) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_pack_model: null parameter pointer");
+    a.p[i] = params[i];
+  }
+  a.out = packed;
+  const int threads = 256;
+  const unsigned blocks = (unsigned)((nerf::kPackedFloats + threads - 1) / threads);
+  hipLaunchKernelGGL(nerf_pack_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, a);
+  return check_launch("nerf_pack_kernel");
+}
+
+int32_t nerf_positional_encoding(const float* x, int64_t n, int32_t n_freqs, float* out, void* stream) {
+  if (n < 0 || n_freqs < 0 || n_freqs > 16) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_positional_encoding: bad size");
+  if (n == 0) return NERF_OK;
+  if (!x || !out) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_positional_encoding: null argument");
+  const unsigned blocks = (unsigned)((n * 3 + 255) / 256);
+  hipLaunchKernelGGL(nerf_pe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)n, n_freqs, out);
+  return check_launch("nerf_pe_kernel");
+}
+
+int32_t nerf_mlp_forward(const float* pts, const float* viewdirs, int64_t n_rays, int32_t n_samples,
+                         const float* packed, float* raw, int32_t precision, void* stream) {
+  if (n_rays < 0 || n_samples <= 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward: bad size");
+  if (n_rays == 0) return NERF_OK;
+  if (!pts || !viewdirs || !packed || !raw) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward: null argument");
+  MlpArgs a{};
+  a.pts = pts; a.viewdirs = viewdirs; a.n_points = n_rays * n_samples; a.n_samples = n_samples;
+  a.packed = packed; a.raw = raw;
+  return launch_mlp(a, false, precision, (hipStream_t)stream);
+}
+
+int32_t nerf_mlp_forward_rays(const float* rays_o, const float* rays_d, const float* tvals,
+                              int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
+                              const float* packed, float* raw, int32_t precision, void* stream) {
+  if (n_rays < 0 || n_samples <= 0 || t_ray_stride < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_rays: bad size");
+  if (n_rays == 0) return NERF_OK;
+  if (!rays_o || !rays_d || !tvals || !packed || !raw) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_rays: null argument");
+  MlpArgs a{};
+  a.rays_o = rays_o; a.rays_d = rays_d; a.tvals = tvals; a.t_ray_stride = t_ray_stride;
+  a.n_points = n_rays * n_samples; a.n_samples = n_samples; a.packed = packed; a.raw = raw;
+  return launch_mlp(a, true, precision, (hipStream_t)stream);
+}
+
+int32_t nerf_sample_fine(const float* raw_coarse, const float* t_coarse, const float* u,
+                         int64_t n_rays, float* t_sorted, float* t_fine, void* stream) {
+  if (n_rays < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_sample_fine: bad size");
+  if (n_rays == 0) return NERF_OK;
+  if (!raw_coarse || !t_coarse || !u || !t_sorted) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_sample_fine: null argument");
+  const unsigned blocks = (unsigned)((n_rays + kSampleThreads - 1) / kSampleThreads);
+  hipLaunchKernelGGL(nerf_sample_fine_kernel, dim3(blocks), dim3(kSampleThreads), 0, (hipStream_t)stream,
+                     raw_coarse, t_coarse, u, (long long)n_rays, t_sorted, t_fine);
+  return check_launch("nerf_sample_fine_kernel");
+}
+
+int32_t nerf_composite(const float* raw, const float* tvals, int64_t t_ray_stride, int64_t n_rays,
+                       int32_t n_samples, int32_t white_bkgd, float* rgb, float* depth,
+                       float* weights, void* stream) {
+  if (n_rays < 0 || n_samples <= 0 || t_ray_stride < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_composite: bad size");
+  if (n_rays == 0) return NERF_OK;
+  if (!raw || !tvals || !rgb || !depth) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_composite: null argument");
+  const unsigned blocks = (unsigned)((n_rays + 255) / 256);
+  hipLaunchKernelGGL(nerf_composite_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, raw, tvals,
+                     (long long)t_ray_stride, (long long)n_rays, n_samples, white_bkgd, rgb, depth, weights);
+  return check_launch("nerf_composite_kernel");
+}
+
+int64_t nerf_render_workspace_bytes(int64_t n_rays, int32_t n_importance) {
+  if (n_rays < 0) return -1;
+  const int64_t raw_c = align256(n_rays * NERF_N_SAMPLES * 4 * (int64_t)sizeof(float));
+  if (n_importance == 0) return raw_c;
+  const int64_t S = NERF_N_SAMPLES + NERF_N_IMPORTANCE;
+  return raw_c + align256(n_rays * S * (int64_t)sizeof(float)) + align256(n_rays * S * 4 * (int64_t)sizeof(float));
+}
+
+int32_t nerf_render_forward(const float* rays_o, const float* rays_d, int64_t n_rays,
+                            const float* packed_coarse, const float* packed_fine,
+                            const float* t_coarse, const float* u, int32_t n_importance,
+                            int32_t white_bkgd, int32_t precision, void* workspace,
+                            int64_t workspace_bytes, float* rgb, float* depth, void* stream) {
+  if (n_rays < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_render_forward: bad size");
+  if (n_importance != 0 && n_importance != NERF_N_IMPORTANCE)
+    return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_render_forward: n_importance must be 0 or 128");
+  if (n_rays == 0) return NERF_OK;
+  if (!rays_o || !rays_d || !packed_coarse || !t_coarse || !rgb || !depth || !workspace ||
+      (n_importance && (!packed_fine || !u)))
+    return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_render_forward: null argument");
+  if (workspace_bytes < nerf_render_workspace_bytes(n_rays, n_importance))
+    return fail(NERF_ERR_WORKSPACE, "%s", "nerf_render_forward: workspace too small");
+  char* ws = (char*)workspace;
+  float* raw_c = (float*)ws;
+  int rc = nerf_mlp_forward_rays(rays_o, rays_d, t_coarse, 0, n_rays, NERF_N_SAMPLES, packed_coarse, raw_c, precision, stream);
+  if (rc) return rc;
+  if (n_importance == 0)
+    return nerf_composite(raw_c, t_coarse, 0, n_rays, NERF_N_SAMPLES, white_bkgd, rgb, depth, nullptr, stream);
+  const int64_t S = NERF_N_SAMPLES + NERF_N_IMPORTANCE;
+  float* t_sorted = (float*)(ws + align256(n_rays * NERF_N_SAMPLES * 4 * (int64_t)sizeof(float)));
+  float* raw_f = (float*)((char*)t_sorted + align256(n_rays * S * (int64_t)sizeof(float)));
+  rc = nerf_sample_fine(raw_c, t_coarse, u, n_rays, t_sorted, nullptr, stream);
+  if (rc) return rc;
+  rc = nerf_mlp_forward_rays(rays_o, rays_d, t_sorted, S, n_rays, (int32_t)S, packed_fine, raw_f, precision, stream);
+  if (rc) return rc;
+  return nerf_composite(raw_f, t_sorted, S, n_rays, (int32_t)S, white_bkgd, rgb, depth, nullptr, stream);
+}
+
+}  // extern "C"

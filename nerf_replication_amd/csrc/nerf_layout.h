@@ -1,0 +1,85 @@
+// Packed-model layout shared by the pack kernel, the MLP kernels and the host code.
+//
+// The fused MLP keeps activations in MFMA accumulator layout from layer to layer:
+// v_mfma_f32_32x32x2_f32 computes D[32 out-features][32 points]; lane l = (p = l&31, h = l>>5)
+// holds, in register r of tile t, feature  act_feat(t,r,h) = 32t + (r&3) + 8(r>>2) + 4h  of
+// point p.  Used as the B operand of the next layer, register r of tile t is exactly the K-pair
+// {act_feat(t,r,0), act_feat(t,r,1)} of k-step s = 16t + r, so no data movement is needed between
+// layers: only the WEIGHTS are permuted, once, on the device (nerf_pack_model), so that the A
+// fragment of (k-step s, out-tile j) is  W[32j + (l&31)][act_feat(t,r,l>>5)].
+//
+// Weight stream: for a layer with KS k-steps and NT out-tiles, float4 index
+//     ((g*NT + j)*64 + lane),  g = s/4, component q = s%4
+// i.e. one 1-KiB wave-coalesced block per (4 k-steps, out-tile), in exactly the order consumed.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define NERF_HD __host__ __device__
+#else
+#define NERF_HD
+#endif
+
+namespace nerf {
+
+constexpr int kHidden = 256;       // network.py:22-32  (W)
+constexpr int kXyzFreqs = 10;      // lego.yaml:39-41
+constexpr int kDirFreqs = 4;       // lego.yaml:42-44
+constexpr int kXyzCh = 63;         // 3 + 6*10
+constexpr int kDirCh = 27;         // 3 + 6*4
+constexpr int kViewsOut = 128;     // network.py:34-36  (W/2)
+constexpr int kTilePts = 32;       // points per wave tile (MFMA N)
+
+NERF_HD constexpr int act_feat(int t, int r, int h) { return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Positional-encoding slot -> reference feature index (freq.py:31-32 ordering:
+// [x(3), sin(2^0 x)(3), cos(2^0 x)(3), sin(2^1 x)(3), ...]).  -1 = zero pad.
+// xyz: 2 tiles = 32 slots per lane-half.  Lane-half h evaluates sincos of args a = 15h + n/2
+// (octave k = a/3, coordinate c = a%3); slots 30,31 carry the raw coordinates.
+NERF_HD constexpr int pe_xyz_feat(int n, int h) {
+  if (n < 30) {
+    int a = 15 * h + n / 2, k = a / 3, c = a % 3;
+    return 3 + 6 * k + 3 * (n & 1) + c;
+  }
+  if (n == 30) return h == 0 ? 0 : 2;
+  return h == 0 ? 1 : -1;
+}
+// view dir: 1 tile = 16 slots per lane-half; args a = 6h + n/2 for n < 12; slots 12,13 raw.
+NERF_HD constexpr int pe_dir_feat(int n, int h) {
+  if (n < 12) {
+    int a = 6 * h + n / 2, k = a / 3, c = a % 3;
+    return 3 + 6 * k + 3 * (n & 1) + c;
+  }
+  if (n == 12) return h == 0 ? 0 : 2;
+  if (n == 13) return h == 0 ? 1 : -1;
+  return -1;
+}
+
+// ---- packed model: offsets in floats -------------------------------------------------------
+constexpr int64_t wsize(int ksteps, int ntiles) { return (int64_t)(ksteps / 4) * ntiles * 64 * 4; }
+
+constexpr int64_t kOffL0 = 0;                                  // pts_linears.0   K=63(pad 64) -> 256
+constexpr int64_t kOffL1 = kOffL0 + wsize(32, 8);              // pts_linears.1..4
+constexpr int64_t kOffL5a = kOffL1 + 4 * wsize(128, 8);        // pts_linears.5, skip (PE) columns 0..62
+constexpr int64_t kOffL5b = kOffL5a + wsize(32, 8);            // pts_linears.5, hidden columns 63..318
+constexpr int64_t kOffL6 = kOffL5b + wsize(128, 8);            // pts_linears.6, .7
+constexpr int64_t kOffFeat = kOffL6 + 2 * wsize(128, 8);       // feature_linear
+constexpr int64_t kOffViews = kOffFeat + wsize(128, 8);        // views_linears.0: 256 feature + 27(pad 32) dir
+constexpr int64_t kOffBias = kOffViews + wsize(144, 4);        // biases: 9 x [2][128] (L0..L7, feature)
+constexpr int64_t kOffBiasViews = kOffBias + 9 * 256;          // [2][64]
+constexpr int64_t kOffWAlpha = kOffBiasViews + 128;            // [2][128]
+constexpr int64_t kOffWRgb = kOffWAlpha + 256;                 // [3][2][64]
+constexpr int64_t kOffHeadBias = kOffWRgb + 384;               // b_rgb[3], b_alpha
+constexpr int64_t kPackedFloats = kOffHeadBias + 4;
+
+// Order of the 24 parameter tensors of one sub-model (reference state_dict order, network.py:22-47)
+enum ParamIdx {
+  P_W0 = 0, P_B0 = 1,           // pts_linears.i -> 2i, 2i+1
+  P_WV = 16, P_BV = 17,         // views_linears.0
+  P_WF = 18, P_BF = 19,         // feature_linear
+  P_WA = 20, P_BA = 21,         // alpha_linear
+  P_WR = 22, P_BR = 23,         // rgb_linear
+  P_COUNT = 24
+};
+
+}  // namespace nerf

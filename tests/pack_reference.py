@@ -1,0 +1,81 @@
+"""Independent numpy statement of the packed weight stream (csrc/nerf_layout.h) used to check
+nerf_pack_model.  Test infrastructure."""
+import numpy as np
+
+
+def act_feat(t, r, h):
+    return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def pe_xyz_feat(n, h):
+    if n < 30:
+        a = 15 * h + n // 2
+        return 3 + 6 * (a // 3) + 3 * (n & 1) + a % 3
+    if n == 30:
+        return 0 if h == 0 else 2
+    return 1 if h == 0 else -1
+
+
+def pe_dir_feat(n, h):
+    if n < 12:
+        a = 6 * h + n // 2
+        return 3 + 6 * (a // 3) + 3 * (n & 1) + a % 3
+    if n == 12:
+        return 0 if h == 0 else 2
+    if n == 13:
+        return 1 if h == 0 else -1
+    return -1
+
+
+def _stream(W, ksteps, ntiles, colmap):
+    """W [out,in]; colmap(s, h) -> input column or -1.  Returns the [ksteps/4, ntiles, 64, 4] stream."""
+    out = np.zeros((ksteps // 4, ntiles, 64, 4), np.float32)
+    for s in range(ksteps):
+        g, q = divmod(s, 4)
+        for h in range(2):
+            c = colmap(s, h)
+            if c < 0:
+                continue
+            for j in range(ntiles):
+                out[g, j, 32 * h:32 * h + 32, q] = W[32 * j:32 * j + 32, c]
+    return out.reshape(-1)
+
+
+def pack_model(sd, prefix):
+    g = lambda n: sd[f"{prefix}.{n}"].detach().cpu().numpy().astype(np.float32)
+    hid = lambda s, h: act_feat(s >> 4, s & 15, h)
+    parts = [_stream(g("pts_linears.0.weight"), 32, 8, pe_xyz_feat)]
+    for i in (1, 2, 3, 4):
+        parts.append(_stream(g(f"pts_linears.{i}.weight"), 128, 8, hid))
+    W5 = g("pts_linears.5.weight")
+    parts.append(_stream(W5, 32, 8, pe_xyz_feat))
+    parts.append(_stream(W5, 128, 8, lambda s, h: 63 + hid(s, h)))
+    for i in (6, 7):
+        parts.append(_stream(g(f"pts_linears.{i}.weight"), 128, 8, hid))
+    parts.append(_stream(g("feature_linear.weight"), 128, 8, hid))
+
+    def views_col(s, h):
+        if s < 128:
+            return hid(s, h)
+        c = pe_dir_feat(s - 128, h)
+        return -1 if c < 0 else 256 + c
+    parts.append(_stream(g("views_linears.0.weight"), 144, 4, views_col))
+
+    def bias_block(b, ntiles):
+        o = np.zeros((2, ntiles * 16), np.float32)
+        for h in range(2):
+            for j in range(ntiles):
+                for r in range(16):
+                    o[h, j * 16 + r] = b[act_feat(j, r, h)]
+        return o.reshape(-1)
+    for i in range(8):
+        parts.append(bias_block(g(f"pts_linears.{i}.bias"), 8))
+    parts.append(bias_block(g("feature_linear.bias"), 8))
+    parts.append(bias_block(g("views_linears.0.bias"), 4))
+    parts.append(bias_block(g("alpha_linear.weight")[0], 8))
+    Wr = g("rgb_linear.weight")
+    for c in range(3):
+        parts.append(bias_block(Wr[c], 4))
+    parts.append(g("rgb_linear.bias"))
+    parts.append(g("alpha_linear.bias"))
+    return np.concatenate(parts)

@@ -1,0 +1,59 @@
+"""CPU checks of the C-ABI library: it builds for gfx950, loads, and exports every symbol that
+include/nerf_mi355x.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "nerf_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nerf_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_the_binding_surface():
+    import nerf_replication_amd._lib as L
+    assert sorted(L.EXPORTS) == _declared_symbols()
+
+
+def test_library_builds_loads_and_exports():
+    import nerf_replication_amd._lib as L
+    L.build()
+    lib = ctypes.CDLL(L.LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(lib, name), name
+    lib.nerf_abi_version.restype = ctypes.c_int32
+    assert lib.nerf_abi_version() == 1
+    lib.nerf_packed_model_floats.restype = ctypes.c_int64
+    # 2 x K=64 layers + 8 x K=256 layers + views (K=288 -> 128) + biases + heads
+    assert lib.nerf_packed_model_floats() == 2 * 64 * 256 + 8 * 256 * 256 + 288 * 128 + 9 * 256 + 128 + 256 + 384 + 4
+    lib.nerf_render_workspace_bytes.restype = ctypes.c_int64
+    lib.nerf_render_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32]
+    assert lib.nerf_render_workspace_bytes(640000, 128) == 640000 * 4864
+    assert lib.nerf_render_workspace_bytes(640000, 0) == 640000 * 1024
+
+
+def test_product_path_has_no_cpu_fallback(synthetic_sd):
+    import torch
+    import nerf_replication_amd as pkg
+    net = pkg.Network()
+    net.load_state_dict(synthetic_sd, strict=True)
+    assert list(net.state_dict().keys()) == list(synthetic_sd.keys())
+    with pytest.raises(pkg._lib.NerfLibraryError):
+        pkg.Renderer(net).render({"rays_o": torch.zeros(1, 4, 3), "rays_d": torch.zeros(1, 4, 3)})
+    if not torch.cuda.is_available():
+        with pytest.raises(pkg._lib.NerfLibraryError):
+            net.packed("")
+
+
+def test_product_never_imports_oracle():
+    pkg_dir = os.path.join(REPO, "nerf_replication_amd")
+    for root, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".inc", ".cpp")):
+                src = open(os.path.join(root, f)).read()
+                assert "nerf_oracle" not in src and "oracle/" not in src, f

@@ -1,0 +1,245 @@
+"""-m gpu: the HIP path, called through the C ABI (ctypes), against the CPU oracle and the golden
+vectors the real reference produced.  Tolerances (fp32 path), stated per SURVEY.md section 8(c):
+    raw MLP outputs     |d| <= 2e-5 * max|ref| per channel  (different fp32 summation order)
+    final image         max|d rgb| <= 1e-4, max|d depth| <= 1e-3, PSNR >= 60 dB
+Bit-exact where the arithmetic is order-free (point construction, merge of sorted depths,
+ray-permutation / chunk invariance).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+import pack_reference
+
+pytestmark = pytest.mark.gpu
+
+RAW_RTOL = 2e-5
+RGB_ATOL = 1e-4
+DEPTH_ATOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import nerf_replication_amd as pkg
+    pkg._lib.load()            # fail loudly if the HIP extension is not there
+    return pkg
+
+
+@pytest.fixture(scope="module")
+def net(amd, synthetic_sd):
+    n = amd.Network()
+    n.load_state_dict(synthetic_sd, strict=True)
+    return n.cuda().eval()
+
+
+def _chan_err(got, ref):
+    ref = ref.double()
+    scale = ref.reshape(-1, ref.shape[-1]).abs().max(0).values.clamp_min(1e-6)
+    return ((got.double().cpu() - ref).abs().reshape(-1, ref.shape[-1]).max(0).values / scale).max().item()
+
+
+def test_library_loaded_from_tree(amd):
+    assert os.path.dirname(amd._lib.LIB_PATH) == os.path.dirname(amd.__file__)
+    assert amd._lib.load().nerf_abi_version() == 1
+
+
+def test_checkpoint_layout_loads(amd, synthetic_sd):
+    ck = torch.load(os.path.join(GOLDEN, "synthetic_ckpt.pth"), weights_only=True)
+    n = amd.Network()
+    n.load_state_dict(ck["net"], strict=True)       # net_utils.py:374-375 layout
+    for k, v in n.state_dict().items():
+        assert torch.equal(v, synthetic_sd[k])
+
+
+@pytest.mark.parametrize("model,prefix", [("", "model"), ("fine", "model_fine")])
+def test_pack_matches_layout_reference(net, synthetic_sd, model, prefix):
+    got = net.packed(model).cpu().numpy()
+    want = pack_reference.pack_model(synthetic_sd, prefix)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+def test_repack_after_parameter_update(net):
+    before = net.packed("").clone()
+    with torch.no_grad():
+        net.model.rgb_linear.bias.add_(1.0)
+    after = net.packed("")
+    assert not torch.equal(before, after)
+    with torch.no_grad():
+        net.model.rgb_linear.bias.sub_(1.0)
+    assert torch.equal(net.packed(""), before)
+
+
+def test_positional_encoding(net, golden):
+    g = golden("pe.npz")
+    xyz = net.embed_fn(g["x"].cuda()).cpu()
+    dirs = net.embeddirs_fn(g["dirs"].cuda()).cpu()
+    assert xyz.shape == (64, 63) and dirs.shape == (64, 27)
+    assert torch.equal(xyz[:, :3], g["x"])
+    assert (xyz - g["pe_xyz"]).abs().max() <= 5e-7      # sin/cos: <= 2 ulp apart (Sleef vs ocml)
+    assert (dirs - g["pe_dir"]).abs().max() <= 5e-7
+
+
+def test_mlp_forward_golden_points(net, golden):
+    g = golden("mlp_layers.npz")
+    pts, vd = g["pts"].cuda(), g["viewdirs"].cuda()
+    # every point has its own direction here: n=128 "rays" of one sample
+    for model, tag in (("", "coarse"), ("fine", "fine")):
+        raw = net.forward(pts[:, None, :], vd, None, model=model)
+        assert raw.shape == (128, 1, 4)
+        assert _chan_err(raw[:, 0], g[f"{tag}_out"]) <= RAW_RTOL
+
+
+def test_network_forward_golden(net, golden):
+    g = golden("network_forward.npz")
+    for model, key in (("", "raw_coarse"), ("fine", "raw_fine")):
+        raw = net.forward(g["pts"].cuda(), g["viewdirs"].cuda(), None, model=model)
+        assert raw.shape == (8, 64, 4)
+        assert _chan_err(raw, g[key]) <= RAW_RTOL
+
+
+def test_network_forward_ragged_and_masked(net, oracle, synthetic_sd):
+    gen = torch.Generator().manual_seed(3)
+    pts = (torch.rand(5, 7, 3, generator=gen) * 2 - 1) * 3      # 35 points: not a multiple of the 32-point tile
+    vd = torch.randn(5, 3, generator=gen)
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+    with torch.no_grad():
+        ref = oracle.network_forward(synthetic_sd, pts, vd, "fine")
+    raw = net.forward(pts.cuda(), vd.cuda(), None, model="fine")
+    assert _chan_err(raw, ref) <= RAW_RTOL
+    mask = torch.rand(5, 7, generator=gen) > 0.4
+    rawm = net.forward(pts.cuda(), vd.cuda(), mask.cuda(), model="fine").cpu()
+    assert torch.all(rawm[~mask] == 0)
+    assert _chan_err(rawm[mask], ref[mask]) <= RAW_RTOL
+    none = net.forward(pts.cuda(), vd.cuda(), torch.zeros(5, 7, dtype=torch.bool).cuda(), model="")
+    assert torch.all(none == 0)
+
+
+def test_mlp_rays_mode_points_bit_exact(amd, net, golden):
+    """Ray mode builds o + d*t and d/||d|| in-kernel; must equal explicit-point mode bit for bit."""
+    g = golden("sampling.npz")
+    lib, L = amd._lib.load(), amd._lib
+    o, d, t = g["rays_o"].cuda(), g["rays_d"].cuda(), g["t_sorted"].cuda().contiguous()
+    raw_rays = torch.empty(256, 192, 4, device="cuda")
+    L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t), 192, 256, 192, L.ptr(net.packed("fine")),
+                                      L.ptr(raw_rays), 0, L.stream_of(o.device)))
+    pts = (g["rays_o"][:, None, :] + g["rays_d"][:, None, :] * g["t_sorted"][:, :, None]).cuda()
+    vd = (g["rays_d"] / torch.norm(g["rays_d"], dim=-1, keepdim=True)).cuda()
+    raw_pts = net.forward(pts, vd, None, model="fine")
+    assert torch.equal(raw_rays, raw_pts)
+    assert _chan_err(raw_rays, g["raw_fine"]) <= RAW_RTOL
+
+
+def test_fine_sampling_stage(amd, golden):
+    g = golden("sampling.npz")
+    lib, L = amd._lib.load(), amd._lib
+    raw_c = g["raw_coarse"].cuda().contiguous()
+    t_c = torch.linspace(2.0, 6.0, 64).cuda()
+    u = torch.linspace(0.0, 1.0, 128).cuda()
+    assert torch.equal(t_c.cpu(), g["t_coarse"][0])
+    t_sorted = torch.empty(256, 192, device="cuda")
+    t_fine = torch.empty(256, 128, device="cuda")
+    L.check(lib.nerf_sample_fine(L.ptr(raw_c), L.ptr(t_c), L.ptr(u), 256, L.ptr(t_sorted), L.ptr(t_fine),
+                                 L.stream_of(raw_c.device)))
+    tf, ts = t_fine.cpu(), t_sorted.cpu()
+    d = (tf - g["t_fine"]).abs()
+    # continuous in the inputs; only the sum order of the 62 weights differs from torch (1-ulp pdf changes,
+    # amplified where a u lands in an almost-empty CDF bin)
+    assert d.max() <= 2e-3 and (d <= 2e-5).float().mean() >= 0.995, (d.max().item(), (d <= 2e-5).float().mean().item())
+    assert torch.equal(tf[:, -1], g["t_fine"][:, -1])                 # F7 tail collapse onto bins[61]
+    # merged output is exactly the sort of (coarse U own fine depths)
+    want, _ = torch.sort(torch.cat([g["t_coarse"], tf], 1), dim=-1)
+    assert torch.equal(ts, want)
+    assert (ts - g["t_sorted"]).abs().max() <= 2e-3
+
+
+def test_composite_stage(amd, oracle, golden):
+    g = golden("sampling.npz")
+    lib, L = amd._lib.load(), amd._lib
+    raw, t = g["raw_fine"].cuda().contiguous(), g["t_sorted"].cuda().contiguous()
+    rgb, dep, w = torch.empty(256, 3, device="cuda"), torch.empty(256, device="cuda"), torch.empty(256, 192, device="cuda")
+    L.check(lib.nerf_composite(L.ptr(raw), L.ptr(t), 192, 256, 192, 1, L.ptr(rgb), L.ptr(dep), L.ptr(w),
+                               L.stream_of(raw.device)))
+    ref_rgb, ref_dep = oracle.composite(g["raw_fine"], g["t_sorted"], True)
+    assert (w.cpu() - g["w192"]).abs().max() <= 2e-6
+    assert (rgb.cpu() - ref_rgb).abs().max() <= 5e-6
+    assert (dep.cpu() - ref_dep).abs().max() <= 2e-5
+    # no white background, coarse table shared by all rays (stride 0)
+    t64 = torch.linspace(2.0, 6.0, 64).cuda()
+    rawc = g["raw_coarse"].cuda().contiguous()
+    rgb0, dep0 = torch.empty(256, 3, device="cuda"), torch.empty(256, device="cuda")
+    L.check(lib.nerf_composite(L.ptr(rawc), L.ptr(t64), 0, 256, 64, 0, L.ptr(rgb0), L.ptr(dep0), None,
+                               L.stream_of(rawc.device)))
+    r0, d0 = oracle.composite(g["raw_coarse"], g["t_coarse"], False)
+    assert (rgb0.cpu() - r0).abs().max() <= 5e-6 and (dep0.cpu() - d0).abs().max() <= 2e-5
+
+
+def _render(amd, net, o, d, n_importance=128):
+    r = amd.Renderer(net)
+    r.N_importance = n_importance
+    with torch.no_grad():
+        return r.render({"rays_o": o.cuda(), "rays_d": d.cuda()})
+
+
+def test_render_golden(amd, net, golden, oracle):
+    g = golden("render.npz")
+    rgb, dep = _render(amd, net, g["rays_o"][None], g["rays_d"][None])
+    assert rgb.shape == (256, 3) and dep.shape == (256,) and rgb.is_cuda
+    assert (rgb.cpu() - g["rgb_128"]).abs().max() <= RGB_ATOL
+    assert (dep.cpu() - g["depth_128"]).abs().max() <= DEPTH_ATOL
+    assert oracle.psnr(rgb.cpu(), g["rgb_128"]) >= 60.0
+    rgb0, dep0 = _render(amd, net, g["rays_o"][None], g["rays_d"][None], n_importance=0)
+    assert (rgb0.cpu() - g["rgb_0"]).abs().max() <= RGB_ATOL
+    assert (dep0.cpu() - g["depth_0"]).abs().max() <= DEPTH_ATOL
+    prgb, pdep = _render(amd, net, g["pin_rays_o"][None], g["pin_rays_d"][None])
+    assert (prgb.cpu() - g["pin_rgb"]).abs().max() <= RGB_ATOL
+    assert (pdep.cpu() - g["pin_depth"]).abs().max() <= DEPTH_ATOL
+    assert oracle.psnr(prgb.cpu(), g["pin_rgb"]) >= 60.0
+
+
+def test_render_batched_layout_and_empty(amd, net, golden):
+    g = golden("render_batched.npz")
+    rgb, dep = _render(amd, net, g["rays_o"], g["rays_d"])
+    assert rgb.shape == (192, 3) and dep.shape == (192,)
+    assert (rgb.cpu() - g["rgb"]).abs().max() <= RGB_ATOL and (dep.cpu() - g["depth"]).abs().max() <= DEPTH_ATOL
+    e_rgb, e_dep = _render(amd, net, torch.zeros(1, 0, 3), torch.zeros(1, 0, 3))
+    assert e_rgb.shape == (0, 3) and e_dep.shape == (0,)
+
+
+def test_render_rejects_cpu_and_bad_args(amd, net):
+    r = amd.Renderer(net)
+    with pytest.raises(amd._lib.NerfLibraryError):
+        r.render({"rays_o": torch.zeros(1, 4, 3), "rays_d": torch.zeros(1, 4, 3)})
+    lib = amd._lib.load()
+    assert lib.nerf_render_forward(None, None, 4, None, None, None, None, 128, 1, 0, None, 0, None, None, None) == -1
+    assert b"null" in lib.nerf_last_error()
+    assert lib.nerf_render_forward(None, None, 4, None, None, None, None, 64, 1, 0, None, 0, None, None, None) == -1
+    assert lib.nerf_render_forward(None, None, 0, None, None, None, None, 128, 1, 0, None, 0, None, None, None) == 0
+    assert lib.nerf_render_workspace_bytes(1000, 128) == 1000 * (1024 + 768 + 3072)
+
+
+def test_full_frame_properties(amd, net, oracle, synthetic_sd):
+    """BASELINE config 2 size (800x800 = 640 000 rays, 64+128): size-independent properties, plus the
+    oracle on a random 512-ray subset."""
+    c2w = oracle.camera_pose(40.0)
+    o, d = oracle.pinhole_rays(800, 800, c2w)
+    rgb, dep = _render(amd, net, o[None], d[None])
+    rgb, dep = rgb.cpu(), dep.cpu()
+    assert rgb.shape == (640000, 3) and torch.isfinite(rgb).all() and torch.isfinite(dep).all()
+    assert rgb.min() >= -1e-6 and rgb.max() <= 1.0 + 1e-5 and dep.min() >= 0 and dep.max() <= 6.0 + 1e-4
+    # rays are independent: a permuted subset, rendered alone, is bit-identical (chunk / tile invariance)
+    gen = torch.Generator().manual_seed(0)
+    idx = torch.randperm(640000, generator=gen)[:4097]
+    rgb_s, dep_s = _render(amd, net, o[idx][None], d[idx][None])
+    assert torch.equal(rgb_s.cpu(), rgb[idx]) and torch.equal(dep_s.cpu(), dep[idx])
+    # determinism
+    rgb2, dep2 = _render(amd, net, o[idx][None], d[idx][None])
+    assert torch.equal(rgb2, rgb_s) and torch.equal(dep2, dep_s)
+    sub = idx[:512]
+    with torch.no_grad():
+        ref_rgb, ref_dep = oracle.render(synthetic_sd, o[sub][None], d[sub][None])
+    assert (rgb[sub] - ref_rgb).abs().max() <= RGB_ATOL and (dep[sub] - ref_dep).abs().max() <= DEPTH_ATOL
+    assert oracle.psnr(rgb[sub], ref_rgb) >= 60.0
