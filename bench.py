@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- rays/sec of the NeRF volume-rendering hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N>1, one rank per GPU)
+
+A "step" is one pass of the hot path over one synthetic 800x800 frame (BASELINE.json configs[1]:
+640 000 rays, 64 coarse + 128 fine samples), rays already resident in HBM.  With N>1 the frame's
+rays are sharded over the ranks (contiguous tiles) and one RCCL all_gather reassembles it: strong
+scaling, as BASELINE.json's north_star asks.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      dominant kernel (nerf_mlp_f32_kernel: both launches of a frame), algorithmic FLOP
+                (1 186 816 per MLP point) / HIP-event time, vs 157.3 TFLOP/s fp32 MFMA
+  cpu_baseline  the CPU oracle (port of the reference, its 512-point chunking) timed on this host
+                on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FLOP_PER_POINT = 1186816                 # 2 x 593 408 MAC, unpadded
+POINTS_PER_RAY = 64 + 192
+PEAK_F32_MFMA = 157.3e12                 # MI355X_MICROARCH.md chip table
+H = W = 800
+
+
+def make_rays(device):
+    """Blender-style pinhole rays of one 800x800 frame, generated on the device (same formula as
+    src/datasets/nerf/blender.py:102-127; float32 here -- bench input, not a parity fixture)."""
+    import math
+    f = W / (2.0 * math.tan(0.6911112070083618 / 2.0))
+    v, u = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float32),
+                          torch.arange(W, device=device, dtype=torch.float32), indexing="ij")
+    dirs = torch.stack([(u - W / 2) / f, -(v - H / 2) / f, -torch.ones_like(u)], -1).reshape(-1, 3)
+    th, ph, rad = math.radians(40.0), math.radians(-30.0), 4.031128874
+    rot_phi = torch.tensor([[1, 0, 0], [0, math.cos(ph), -math.sin(ph)], [0, math.sin(ph), math.cos(ph)]])
+    rot_th = torch.tensor([[math.cos(th), 0, -math.sin(th)], [0, 1, 0], [math.sin(th), 0, math.cos(th)]])
+    flip = torch.tensor([[-1.0, 0, 0], [0, 0, 1], [0, 1, 0]])
+    R = (flip @ rot_th @ rot_phi).to(device)
+    origin = R @ torch.tensor([0.0, 0.0, rad], device=device)
+    d = dirs @ R.T
+    d = d / d.norm(dim=-1, keepdim=True)
+    return origin.expand_as(d).contiguous(), d.contiguous()
+
+
+def load_weights():
+    ck = torch.load(os.path.join(REPO, "tests", "golden", "synthetic_ckpt.pth"), weights_only=True)
+    return ck["net"]
+
+
+def time_stages(pkg, net, ren, o, d, steps):
+    """HIP-event time of each kernel of the render path, launched through the C ABI on torch's
+    current stream (the stream the events are recorded on)."""
+    L, lib = pkg._lib, pkg._lib.load()
+    n, dev = o.shape[0], o.device
+    t_c, u = ren._get_tables(dev)
+    pk_c, pk_f = net.packed(""), net.packed("fine")
+    raw_c = torch.empty(n, 64, 4, device=dev)
+    t_sorted = torch.empty(n, 192, device=dev)
+    raw_f = torch.empty(n, 192, 4, device=dev)
+    rgb, dep = torch.empty(n, 3, device=dev), torch.empty(n, device=dev)
+    st = L.stream_of(dev)
+    names = ["mlp_coarse", "sample_fine", "mlp_fine", "composite"]
+    acc = dict.fromkeys(names, 0.0)
+    for _ in range(steps):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev[0].record()
+        L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t_c), 0, n, 64, L.ptr(pk_c), L.ptr(raw_c), 0, st))
+        ev[1].record()
+        L.check(lib.nerf_sample_fine(L.ptr(raw_c), L.ptr(t_c), L.ptr(u), n, L.ptr(t_sorted), None, st))
+        ev[2].record()
+        L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t_sorted), 192, n, 192, L.ptr(pk_f), L.ptr(raw_f), 0, st))
+        ev[3].record()
+        L.check(lib.nerf_composite(L.ptr(raw_f), L.ptr(t_sorted), 192, n, 192, 1, L.ptr(rgb), L.ptr(dep), None, st))
+        ev[4].record()
+        torch.cuda.synchronize()
+        for i, k in enumerate(names):
+            acc[k] += ev[i].elapsed_time(ev[i + 1])
+    return {k: v / steps for k, v in acc.items()}
+
+
+def cpu_baseline(sd, n_sample):
+    """The CPU oracle (port of the reference incl. its 512-point MLP chunking) on `n_sample` rays of
+    the same frame, all host cores.  Checker code used as the reported baseline, never as product."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import nerf_oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ids = torch.randperm(H * W, generator=torch.Generator().manual_seed(0))[:n_sample]
+    o, d = orc.pinhole_rays(H, W, orc.camera_pose(40.0), pixel_ids=ids)
+    with torch.no_grad():
+        orc.render(sd, o[None, :256], d[None, :256])              # warm-up
+        t0 = time.perf_counter()
+        rgb, dep = orc.render(sd, o[None], d[None])
+        dt = time.perf_counter() - t0
+    return {"value": n_sample / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_sample} random rays of the same 800x800 frame, 64+128, oracle/nerf_oracle.py "
+                      f"(torch CPU fp32, 512-point MLP chunks), {dt:.1f} s, os.cpu_count()={cores}"}, (ids, rgb, dep)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu-sample", type=int, default=8192, help="rays in the bounded CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 as: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import nerf_replication_amd as pkg
+    from nerf_replication_amd.dist import render_sharded, shard_bounds
+    pkg._lib.load()                                   # fail loudly without the HIP extension
+    sd = load_weights()
+    net = pkg.Network()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    ren = pkg.Renderer(net)
+    o, d = make_rays(dev)
+    n = o.shape[0]
+
+    def step():
+        with torch.no_grad():
+            return render_sharded(ren, o, d)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rgb, dep = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n * args.steps / elapsed
+
+    # dominant-kernel roofline on this rank's shard (HIP events on the launch stream)
+    lo, hi, _ = shard_bounds(n, rank, world)
+    stages = time_stages(pkg, net, ren, o[lo:hi].contiguous(), d[lo:hi].contiguous(), max(1, min(args.steps, 3)))
+    mlp_ms_per_launch = (stages["mlp_coarse"] + stages["mlp_fine"]) / 2.0
+    flop_per_launch = (hi - lo) * POINTS_PER_RAY * FLOP_PER_POINT / 2.0
+    achieved = flop_per_launch / (mlp_ms_per_launch * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+                "frac": round(achieved / (PEAK_F32_MFMA / 1e12), 4), "traffic": None,
+                "kernel": "nerf_mlp_f32_kernel", "avg_launch_ms": round(mlp_ms_per_launch, 3),
+                "stage_ms": {k: round(v, 3) for k, v in stages.items()}}
+
+    if rank == 0:
+        out = {"metric": "rays/sec (800x800, 64+128 samples)", "value": round(value, 1), "unit": "rays/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic",
+               "config": {"workload": "lego-shaped 800x800 frame = 640000 pinhole rays, 64 coarse + 128 fine "
+                                      "hierarchical samples, 8+1-layer W=256 NeRF x2, seeded synthetic weights "
+                                      "(latest.pth unavailable offline); BASELINE.json configs[1]",
+                          "rays_per_step": n, "parallelism": f"ray-tile shard x{world} + 1 all_gather"},
+               "roofline": roofline}
+        if world == 1 and args.cpu_sample > 0:
+            base, (ids, ref_rgb, ref_dep) = cpu_baseline(sd, args.cpu_sample)
+            base["value"] = round(base["value"], 1)
+            out["cpu_baseline"] = base
+            sys.path.insert(0, os.path.join(REPO, "oracle"))
+            import nerf_oracle as orc
+            # the oracle rays are the float64-built fixtures' formula; re-render exactly those rays for PSNR
+            oo, dd = orc.pinhole_rays(H, W, orc.camera_pose(40.0), pixel_ids=ids)
+            with torch.no_grad():
+                g_rgb, g_dep = ren.render({"rays_o": oo[None].to(dev), "rays_d": dd[None].to(dev)})
+            out["psnr_vs_cpu_oracle_db"] = round(orc.psnr(g_rgb.cpu(), ref_rgb), 1)
+            out["speedup_vs_cpu_baseline"] = round(value / base["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,13 +72,15 @@ def state_dict_keys():
     return [f"{m}.{k}" for m in ("model", "model_fine") for k in SUBMODEL_KEYS]
 
 
-def synthetic_state_dict(seed: int = 0, occupied: float = 0.15, sigma_std: float = 8.0,
-                         rgb_std: float = 1.5, fine_jitter: float = 0.02):
+def synthetic_state_dict(seed: int = 0, occupied: float = 0.3, sigma_std: float = 8.0,
+                         rgb_std: float = 1.5, fine_jitter: float = 0.02, octave_decay: float = 1.0):
     """Seeded stand-in for latest.pth (unavailable offline): a random but scene-like field.
 
     nn.Linear-style uniform(-1/sqrt(fan_in), 1/sqrt(fan_in)) init for the coarse model; the
     fine model is the coarse one with `fine_jitter` relative noise (as in a trained NeRF both
-    describe the same scene).  The density and colour heads are then rescaled against a seeded
+    describe the same scene).  Input columns of positional-encoding octave k are damped by
+    2^(-octave_decay*k) (the spectral bias of a trained NeRF: a band-limited, scene-like field
+    instead of white noise).  The density and colour heads are then rescaled against a seeded
     probe set so that about `occupied` of space has sigma > 0 (std `sigma_std`) and the
     pre-sigmoid colours have std `rgb_std` -- rays get varied opacity, depth and colour.
     """
@@ -89,6 +91,9 @@ def synthetic_state_dict(seed: int = 0, occupied: float = 0.15, sigma_std: float
         wshape = SUBMODEL_SHAPES[k.replace("bias", "weight")]
         bound = 1.0 / math.sqrt(wshape[1])
         sd[f"model.{k}"] = (torch.rand(shape, generator=g) * 2 - 1) * bound
+    for k in range(XYZ_FREQS):                      # xyz PE columns feed pts_linears.0 and the skip into .5
+        sd["model.pts_linears.0.weight"][:, 3 + 6 * k:9 + 6 * k] *= 2.0 ** (-octave_decay * k)
+        sd["model.pts_linears.5.weight"][:, 3 + 6 * k:9 + 6 * k] *= 2.0 ** (-octave_decay * k)
     # calibrate heads on probe points inside the near/far shell around the origin
     probe = (torch.rand(4096, 3, generator=g) * 2 - 1) * 2.0
     pdir = torch.randn(4096, 3, generator=g)

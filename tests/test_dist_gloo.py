@@ -1,0 +1,80 @@
+"""World-size-2 gloo test of the ray-shard + all_gather frame path (runs on CPU).  The renderer
+is replaced by a stub that calls the CPU oracle (test-only): what is under test is the sharding,
+padding and gather logic of nerf_replication_amd.dist, which is device-agnostic."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO, GOLDEN
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _OracleRenderer:
+    def __init__(self, sd):
+        import nerf_oracle
+        self.orc, self.sd = nerf_oracle, sd
+
+    def render(self, batch):
+        with torch.no_grad():
+            return self.orc.render(self.sd, batch["rays_o"], batch["rays_d"], n_importance=0)
+
+
+def _worker(rank, world, port, n_rays, out_dir):
+    import sys
+    for p in (REPO, os.path.join(REPO, "oracle"), os.path.join(REPO, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nerf_replication_amd.dist import render_sharded, shard_bounds
+        import nerf_oracle as orc
+        sd = torch.load(os.path.join(GOLDEN, "synthetic_ckpt.pth"), weights_only=True)["net"]
+        ids = torch.randperm(800 * 800, generator=torch.Generator().manual_seed(4))[:n_rays]
+        o, d = orc.pinhole_rays(800, 800, orc.camera_pose(10.0), pixel_ids=ids)
+        ren = _OracleRenderer(sd)
+        rgb, dep = render_sharded(ren, o, d)
+        assert rgb.shape == (n_rays, 3) and dep.shape == (n_rays,)
+        lo, hi, per = shard_bounds(n_rays, rank, world)
+        assert 0 <= lo <= hi <= n_rays and hi - lo <= per
+        torch.save({"rgb": rgb, "dep": dep, "lo": lo, "hi": hi}, os.path.join(out_dir, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, n_rays, tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_rays, str(tmp_path)), nprocs=world, join=True)
+    return [torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
+
+
+def test_two_rank_frame_equals_single_process(tmp_path, oracle, synthetic_sd):
+    n_rays = 101                                   # odd: shards of 51 and 50, one padded slot
+    outs = _run(2, n_rays, tmp_path)
+    ids = torch.randperm(800 * 800, generator=torch.Generator().manual_seed(4))[:n_rays]
+    o, d = oracle.pinhole_rays(800, 800, oracle.camera_pose(10.0), pixel_ids=ids)
+    with torch.no_grad():
+        ref_rgb, ref_dep = oracle.render(synthetic_sd, o[None], d[None], n_importance=0)
+    assert (outs[0]["lo"], outs[0]["hi"], outs[1]["lo"], outs[1]["hi"]) == (0, 51, 51, 101)
+    for r in range(2):                             # every rank holds the whole, identical frame
+        assert torch.equal(outs[r]["rgb"], outs[0]["rgb"]) and torch.equal(outs[r]["dep"], outs[0]["dep"])
+        assert torch.allclose(outs[r]["rgb"], ref_rgb, atol=1e-6) and torch.allclose(outs[r]["dep"], ref_dep, atol=1e-5)
+
+
+def test_shard_bounds_cover_every_ray_once():
+    from nerf_replication_amd.dist import shard_bounds
+    for n in (0, 1, 7, 8, 9, 640000, 2560000 + 3):
+        for world in (1, 2, 3, 4, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            assert all(hi - lo <= per for lo, hi, per in spans)
