@@ -88,23 +88,44 @@ def time_stages(pkg, net, ren, o, d, steps):
     return {k: v / steps for k, v in acc.items()}
 
 
-def cpu_baseline(sd, n_sample):
-    """The CPU oracle (port of the reference incl. its 512-point MLP chunking) on `n_sample` rays of
-    the same frame, all host cores.  Checker code used as the reported baseline, never as product."""
+def host_cores():
+    """CPU threads this process may really use: affinity mask, cgroup quota, and the GPU box's
+    per-GPU CPU share (16) -- os.cpu_count() alone reports the whole host."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(sd, n_sample, budget_s=20.0):
+    """The CPU oracle (port of the reference incl. its 512-point MLP chunking) on a bounded sample of
+    rays of the same frame.  Checker code used as the reported baseline, never as product."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import nerf_oracle as orc
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     ids = torch.randperm(H * W, generator=torch.Generator().manual_seed(0))[:n_sample]
     o, d = orc.pinhole_rays(H, W, orc.camera_pose(40.0), pixel_ids=ids)
     with torch.no_grad():
-        orc.render(sd, o[None, :256], d[None, :256])              # warm-up
+        orc.render(sd, o[None, :128], d[None, :128])              # warm-up
+        t0 = time.perf_counter()
+        orc.render(sd, o[None, :512], d[None, :512])              # probe -> size the sample to the budget
+        probe = time.perf_counter() - t0
+        n_sample = int(max(512, min(n_sample, 512 * budget_s / max(probe, 1e-3)))) // 512 * 512
+        ids, o, d = ids[:n_sample], o[:n_sample], d[:n_sample]
+        print(f"[bench] cpu_baseline: probe 512 rays {probe:.2f} s on {cores} threads -> sample {n_sample} rays",
+              file=sys.stderr, flush=True)
         t0 = time.perf_counter()
         rgb, dep = orc.render(sd, o[None], d[None])
         dt = time.perf_counter() - t0
     return {"value": n_sample / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n_sample} random rays of the same 800x800 frame, 64+128, oracle/nerf_oracle.py "
-                      f"(torch CPU fp32, 512-point MLP chunks), {dt:.1f} s, os.cpu_count()={cores}"}, (ids, rgb, dep)
+                      f"(torch CPU fp32, 512-point MLP chunks), {dt:.1f} s, {cores} threads "
+                      f"(os.cpu_count()={os.cpu_count()})"}, (ids, rgb, dep)
 
 
 def main():
@@ -162,6 +183,8 @@ def main():
         elapsed = t.item()
     ms_per_step = elapsed / args.steps * 1e3
     value = n * args.steps / elapsed
+    if rank == 0:
+        print(f"[bench] {args.steps} steps: {ms_per_step:.1f} ms/step, {value:.0f} rays/s", file=sys.stderr, flush=True)
 
     # dominant-kernel roofline on this rank's shard (HIP events on the launch stream)
     lo, hi, _ = shard_bounds(n, rank, world)
