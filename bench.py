@@ -192,8 +192,15 @@ def main():
     mlp_ms_per_launch = (stages["mlp_coarse"] + stages["mlp_fine"]) / 2.0
     flop_per_launch = (hi - lo) * POINTS_PER_RAY * FLOP_PER_POINT / 2.0
     achieved = flop_per_launch / (mlp_ms_per_launch * 1e-3) / 1e12
+    traffic, traffic_src = None, None
+    try:      # HBM bytes per launch come from separate rocprofv3 --pmc passes (cannot be read in-process);
+        tj = json.load(open(os.path.join(REPO, "profiles", "traffic_f32.json")))   # reported only for the profiled workload
+        if world == 1:
+            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/traffic_f32.json (rocprofv3 --pmc, not this run)"
+    except (OSError, ValueError, KeyError):
+        pass
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
-                "frac": round(achieved / (PEAK_F32_MFMA / 1e12), 4), "traffic": None,
+                "frac": round(achieved / (PEAK_F32_MFMA / 1e12), 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "nerf_mlp_f32_kernel", "avg_launch_ms": round(mlp_ms_per_launch, 3),
                 "stage_ms": {k: round(v, 3) for k, v in stages.items()}}
 
