@@ -30,6 +30,7 @@ sys.path.insert(0, REPO)
 FLOP_PER_POINT = 1186816                 # 2 x 593 408 MAC, unpadded
 POINTS_PER_RAY = 64 + 192
 PEAK_F32_MFMA = 157.3e12                 # MI355X_MICROARCH.md chip table
+PEAK_F16_MFMA = 2.5e15                   # dense fp16/bf16 MFMA, same table
 H = W = 800
 
 
@@ -57,7 +58,7 @@ def load_weights():
     return ck["net"]
 
 
-def time_stages(pkg, net, ren, o, d, steps):
+def time_stages(pkg, net, ren, o, d, steps, prec=0):
     """HIP-event time of each kernel of the render path, launched through the C ABI on torch's
     current stream (the stream the events are recorded on)."""
     L, lib = pkg._lib, pkg._lib.load()
@@ -74,11 +75,11 @@ def time_stages(pkg, net, ren, o, d, steps):
     for _ in range(steps):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record()
-        L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t_c), 0, n, 64, L.ptr(pk_c), L.ptr(raw_c), 0, st))
+        L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t_c), 0, n, 64, pk_c.data_ptr(), L.ptr(raw_c), prec, st))
         ev[1].record()
         L.check(lib.nerf_sample_fine(L.ptr(raw_c), L.ptr(t_c), L.ptr(u), n, L.ptr(t_sorted), None, st))
         ev[2].record()
-        L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t_sorted), 192, n, 192, L.ptr(pk_f), L.ptr(raw_f), 0, st))
+        L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t_sorted), 192, n, 192, pk_f.data_ptr(), L.ptr(raw_f), prec, st))
         ev[3].record()
         L.check(lib.nerf_composite(L.ptr(raw_f), L.ptr(t_sorted), 192, n, 192, 1, L.ptr(rgb), L.ptr(dep), None, st))
         ev[4].record()
@@ -134,6 +135,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=8192, help="rays in the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
+                    help="f32 (default, the reference's dtype: exact fp32 MFMA) or f16 (BASELINE config 5: fp16 "
+                         "activations, fp32 accumulate)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,6 +160,9 @@ def main():
     net = pkg.Network()
     net.load_state_dict(sd, strict=True)
     net = net.to(dev).eval()
+    net.precision = args.precision
+    prec = pkg._lib.PRECISIONS[args.precision]
+    peak = PEAK_F32_MFMA if prec == 0 else PEAK_F16_MFMA
     ren = pkg.Renderer(net)
     o, d = make_rays(dev)
     n = o.shape[0]
@@ -188,26 +195,27 @@ def main():
 
     # dominant-kernel roofline on this rank's shard (HIP events on the launch stream)
     lo, hi, _ = shard_bounds(n, rank, world)
-    stages = time_stages(pkg, net, ren, o[lo:hi].contiguous(), d[lo:hi].contiguous(), max(1, min(args.steps, 3)))
+    stages = time_stages(pkg, net, ren, o[lo:hi].contiguous(), d[lo:hi].contiguous(), max(1, min(args.steps, 3)), prec)
     mlp_ms_per_launch = (stages["mlp_coarse"] + stages["mlp_fine"]) / 2.0
     flop_per_launch = (hi - lo) * POINTS_PER_RAY * FLOP_PER_POINT / 2.0
     achieved = flop_per_launch / (mlp_ms_per_launch * 1e-3) / 1e12
     traffic, traffic_src = None, None
     try:      # HBM bytes per launch come from separate rocprofv3 --pmc passes (cannot be read in-process);
-        tj = json.load(open(os.path.join(REPO, "profiles", "traffic_f32.json")))   # reported only for the profiled workload
+        tj = json.load(open(os.path.join(REPO, "profiles", f"traffic_{args.precision}.json")))   # only for the profiled workload
         if world == 1:
-            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/traffic_f32.json (rocprofv3 --pmc, not this run)"
+            traffic, traffic_src = tj["traffic_bytes_per_launch"], f"profiles/traffic_{args.precision}.json (rocprofv3 --pmc, not this run)"
     except (OSError, ValueError, KeyError):
         pass
-    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
-                "frac": round(achieved / (PEAK_F32_MFMA / 1e12), 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "nerf_mlp_f32_kernel", "avg_launch_ms": round(mlp_ms_per_launch, 3),
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+                "frac": round(achieved / (peak / 1e12), 4), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": f"nerf_mlp_{args.precision}_kernel", "avg_launch_ms": round(mlp_ms_per_launch, 3),
                 "stage_ms": {k: round(v, 3) for k, v in stages.items()}}
 
     if rank == 0:
         out = {"metric": "rays/sec (800x800, 64+128 samples)", "value": round(value, 1), "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f32" if prec == 0 else "f16 (fp32 accumulate)",
                "data": "synthetic",
                "config": {"workload": "lego-shaped 800x800 frame = 640000 pinhole rays, 64 coarse + 128 fine "
                                       "hierarchical samples, 8+1-layer W=256 NeRF x2, seeded synthetic weights "

@@ -34,7 +34,9 @@ enum nerf_status {
 };
 
 enum nerf_precision {
-  NERF_PREC_F32 = 0            /* exact fp32: v_mfma_f32_32x32x2_f32 (the parity path) */
+  NERF_PREC_F32 = 0,           /* exact fp32: v_mfma_f32_32x32x2_f32 (the parity path) */
+  NERF_PREC_F16 = 1            /* fp16 activations+weights, fp32 accumulate: v_mfma_f32_32x32x16_f16
+                                  (BASELINE config 5; PSNR-level tolerance, not the parity path) */
 };
 
 /* Renderer constants the reference effectively hard-codes (volume_renderer.py:14-24). */
@@ -44,15 +46,15 @@ enum nerf_precision {
 int32_t nerf_abi_version(void);
 const char* nerf_last_error(void);
 
-/* Number of floats of one packed sub-model (coarse or fine). */
-int64_t nerf_packed_model_floats(void);
+/* Size in bytes of one packed sub-model (coarse or fine) for a precision; -1 if unknown. */
+int64_t nerf_packed_model_bytes(int32_t precision);
 
 /* Permute the 24 parameter tensors of one NeRF sub-model into the kernel's weight stream
  * (csrc/nerf_layout.h).  `params` is a HOST array of 24 DEVICE pointers in the reference's
  * state_dict order (network.py:22-47): pts_linears.0..7 {weight,bias}, views_linears.0,
  * feature_linear, alpha_linear, rgb_linear; weights are nn.Linear [out,in] row-major.
  * Runs on the device; call again whenever the parameters change (e.g. after an optimizer step). */
-int32_t nerf_pack_model(const float* const params[24], float* packed, void* stream);
+int32_t nerf_pack_model(const float* const params[24], void* packed, int32_t precision, void* stream);
 
 /* Positional encoding alone: x [n,3] -> out [n, 3+6*n_freqs] in the reference's channel order.
  * Replaces freq.py:31-32 (Encoder.embed); n_freqs is 10 (xyz) or 4 (view dir). Uses the same
@@ -63,14 +65,14 @@ int32_t nerf_positional_encoding(const float* x, int64_t n, int32_t n_freqs, flo
  * pre-activation.  Replaces network.py:216-256: PE of points and directions, the batchify(512) loop
  * over NeRF.forward (network.py:49-74), and the reshape.  `packed` selects coarse or fine model. */
 int32_t nerf_mlp_forward(const float* pts, const float* viewdirs, int64_t n_rays, int32_t n_samples,
-                         const float* packed, float* raw, int32_t precision, void* stream);
+                         const void* packed, float* raw, int32_t precision, void* stream);
 
 /* Same network on points generated on the fly: pts = rays_o + rays_d * t (volume_renderer.py:63,
  * :267), viewdirs = rays_d / ||rays_d|| (:314).  t of (ray i, sample s) is
  * tvals[i*t_ray_stride + s]; t_ray_stride = 0 shares one table (the deterministic coarse linspace). */
 int32_t nerf_mlp_forward_rays(const float* rays_o, const float* rays_d, const float* tvals,
                               int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
-                              const float* packed, float* raw, int32_t precision, void* stream);
+                              const void* packed, float* raw, int32_t precision, void* stream);
 
 /* Hierarchical sampling + merge.  raw_coarse [n,64,4] (sigma = channel 3, pre-ReLU), t_coarse [64],
  * u [128] -> t_sorted [n,192] (ascending union of coarse and fine depths), optional t_fine [n,128].
@@ -95,7 +97,7 @@ int64_t nerf_render_workspace_bytes(int64_t n_rays, int32_t n_importance);
  * and u [128] are the host-built torch.linspace tables (bit-sensitive).
  * Outputs rgb [n,3], depth [n]. */
 int32_t nerf_render_forward(const float* rays_o, const float* rays_d, int64_t n_rays,
-                            const float* packed_coarse, const float* packed_fine,
+                            const void* packed_coarse, const void* packed_fine,
                             const float* t_coarse, const float* u, int32_t n_importance,
                             int32_t white_bkgd, int32_t precision, void* workspace,
                             int64_t workspace_bytes, float* rgb, float* depth, void* stream);

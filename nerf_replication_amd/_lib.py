@@ -13,15 +13,16 @@ CSRC = os.path.join(_HERE, "csrc")
 N_SAMPLES = 64
 N_IMPORTANCE = 128
 PREC_F32 = 0
-PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32}
+PREC_F16 = 1
+PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "f16": PREC_F16, "fp16": PREC_F16}
 
 _c = ctypes
 _F = _c.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _PROTOS = {
     "nerf_abi_version": (_c.c_int32, []),
     "nerf_last_error": (_c.c_char_p, []),
-    "nerf_packed_model_floats": (_c.c_int64, []),
-    "nerf_pack_model": (_c.c_int32, [_c.POINTER(_c.c_void_p), _F, _c.c_void_p]),
+    "nerf_packed_model_bytes": (_c.c_int64, [_c.c_int32]),
+    "nerf_pack_model": (_c.c_int32, [_c.POINTER(_c.c_void_p), _F, _c.c_int32, _c.c_void_p]),
     "nerf_positional_encoding": (_c.c_int32, [_F, _c.c_int64, _c.c_int32, _F, _c.c_void_p]),
     "nerf_mlp_forward": (_c.c_int32, [_F, _F, _c.c_int64, _c.c_int32, _F, _F, _c.c_int32, _c.c_void_p]),
     "nerf_mlp_forward_rays": (_c.c_int32, [_F, _F, _F, _c.c_int64, _c.c_int64, _c.c_int32, _F, _F,
@@ -76,14 +77,14 @@ def check(rc: int, what: str = ""):
         raise NerfLibraryError(f"{what or 'nerf call'} failed (status {rc}): {msg}")
 
 
-def ptr(t):
-    """Device pointer of a contiguous fp32 CUDA tensor (None -> NULL)."""
+def ptr(t, dtype=torch.float32):
+    """Device pointer of a contiguous CUDA tensor of `dtype` (None -> NULL)."""
     if t is None:
         return None
     if not t.is_cuda:
         raise NerfLibraryError("the HIP render path needs tensors on a GPU (cuda) device; got a CPU tensor")
-    if t.dtype != torch.float32 or not t.is_contiguous():
-        raise NerfLibraryError("expected a contiguous float32 tensor")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise NerfLibraryError(f"expected a contiguous {dtype} tensor")
     return t.data_ptr()
 
 
@@ -91,5 +92,8 @@ def stream_of(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def packed_model_floats() -> int:
-    return int(load().nerf_packed_model_floats())
+def packed_model_bytes(precision: int) -> int:
+    n = int(load().nerf_packed_model_bytes(precision))
+    if n <= 0:
+        raise NerfLibraryError(f"unknown precision {precision}")
+    return n

@@ -7,6 +7,7 @@
 #include "../../include/nerf_mi355x.h"
 #include "nerf_layout.h"
 #include "nerf_mlp_f32.hip.inc"
+#include "nerf_mlp_f16.hip.inc"
 
 namespace {
 
@@ -87,6 +88,64 @@ __global__ void nerf_pack_kernel(PackArgs a) {
     v = rel < 3 ? a.p[P_BR][rel] : a.p[P_BA][0];
   }
   a.out[i] = v;
+}
+
+// fp16 stream (nerf_layout.h "fp16-activation path"): const region (fp32 biases) + A fragments
+__global__ void nerf_pack_f16_kernel(PackArgs a) {
+  using namespace nerf;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr long long n_const = kF16ConstBytes / 4;
+  constexpr long long n_half = (long long)kF16Frags * 512;
+  if (i < n_const) {                     // const region, floats
+    float v = 0.0f;
+    if (i < kF16OffBiasViews) {
+      const int rel = (int)i, layer = rel >> 8, h = (rel >> 7) & 1, slot = rel & 127;
+      const float* b = layer < 8 ? a.p[2 * layer + 1] : a.p[P_BF];
+      v = b[act_feat(slot >> 4, slot & 15, h)];
+    } else if (i < kF16OffHeadBias) {
+      const int rel = (int)i - kF16OffBiasViews, h = rel >> 6, slot = rel & 63;
+      v = a.p[P_BV][act_feat(slot >> 4, slot & 15, h)];
+    } else if (i < kF16OffHeadBias + 4) {
+      const int rel = (int)i - kF16OffHeadBias;
+      v = rel < 3 ? a.p[P_BR][rel] : a.p[P_BA][0];
+    }
+    a.out[i] = v;
+    return;
+  }
+  const long long e = i - n_const;
+  if (e >= n_half) return;
+  const int F = (int)(e >> 9), lane = (int)((e >> 3) & 63), j = (int)(e & 7);
+  const int h = lane >> 5, row = lane & 31;
+  const int cj = (j & 3) + 8 * (j >> 2) + 4 * h;              // act16_feat(s,j,h) - 16 s
+  float v = 0.0f;
+  if (F < kF16FragL1) {                                       // L0: 8 m x 4 PE k-steps
+    const int m = F >> 2, s = F & 3, c = pe_xyz_feat(8 * s + j, h);
+    if (c >= 0) v = a.p[P_W0][(32 * m + row) * 63 + c];
+  } else if (F < kF16FragL5) {                                // L1..L4
+    const int f = F - kF16FragL1, li = 1 + (f >> 7), m = (f & 127) >> 4, s = f & 15;
+    v = a.p[2 * li][(32 * m + row) * 256 + 16 * s + cj];
+  } else if (F < kF16FragL6) {                                // L5: 4 PE + 16 hidden k-steps per m
+    const int f = F - kF16FragL5, m = f / 20, s = f % 20;
+    if (s < 4) { const int c = pe_xyz_feat(8 * s + j, h); if (c >= 0) v = a.p[10][(32 * m + row) * 319 + c]; }
+    else v = a.p[10][(32 * m + row) * 319 + 63 + 16 * (s - 4) + cj];
+  } else if (F < kF16FragFeat) {                              // L6, L7
+    const int f = F - kF16FragL6, li = 6 + (f >> 7), m = (f & 127) >> 4, s = f & 15;
+    v = a.p[2 * li][(32 * m + row) * 256 + 16 * s + cj];
+  } else if (F < kF16FragSigma) {                             // feature
+    const int f = F - kF16FragFeat, m = f >> 4, s = f & 15;
+    v = a.p[P_WF][(32 * m + row) * 256 + 16 * s + cj];
+  } else if (F < kF16FragViews) {                             // sigma head: row 0 only
+    const int s = F - kF16FragSigma;
+    if (row == 0) v = a.p[P_WA][16 * s + cj];
+  } else if (F < kF16FragRgb) {                               // views: 16 feature + 2 dir k-steps per m
+    const int f = F - kF16FragViews, m = f / 18, s = f % 18;
+    if (s < 16) v = a.p[P_WV][(32 * m + row) * 283 + 16 * s + cj];
+    else { const int c = pe_dir_feat(8 * (s - 16) + j, h); if (c >= 0) v = a.p[P_WV][(32 * m + row) * 283 + 256 + c]; }
+  } else {                                                    // rgb head: rows 0..2
+    const int s = F - kF16FragRgb;
+    if (row < 3) v = a.p[P_WR][row * 128 + 16 * s + cj];
+  }
+  reinterpret_cast<_Float16*>(reinterpret_cast<char*>(a.out) + kF16ConstBytes)[e] = (_Float16)v;
 }
 
 // ------------------------------------------------------------------------------------ PE (test entry)
@@ -229,9 +288,27 @@ void nerf_composite_kernel(const float* __restrict__ raw, const float* __restric
 }
 
 // ------------------------------------------------------------------------------------ launch helpers
+int num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    cus = v;
+  }
+  return cus;
+}
+
 int launch_mlp(const MlpArgs& a, bool ray_mode, int precision, hipStream_t st) {
-  if (precision != NERF_PREC_F32) return fail(NERF_ERR_UNSUPPORTED, "%s", "precision not built");
+  if (precision != NERF_PREC_F32 && precision != NERF_PREC_F16) return fail(NERF_ERR_UNSUPPORTED, "%s", "precision not built");
   if (a.n_points <= 0) return NERF_OK;
+  if (precision == NERF_PREC_F16) {        // persistent workgroups, one per CU (147 KB of LDS each)
+    const long long n_tiles = (a.n_points + kF16TilePts - 1) / kF16TilePts;
+    const unsigned blocks = (unsigned)(n_tiles < num_cus() ? n_tiles : num_cus());
+    if (ray_mode) hipLaunchKernelGGL(nerf_mlp_f16_kernel<true>, dim3(blocks), dim3(kF16Threads), 0, st, a);
+    else hipLaunchKernelGGL(nerf_mlp_f16_kernel<false>, dim3(blocks), dim3(kF16Threads), 0, st, a);
+    return check_launch("nerf_mlp_f16_kernel");
+  }
   const long long tiles = (a.n_points + nerf::kTilePts - 1) / nerf::kTilePts;
   const long long blocks = (tiles + 3) / 4;
   if (blocks > 0x7fffffffLL) return fail(NERF_ERR_INVALID_ARG, "%s", "too many points for one launch");
@@ -249,17 +326,27 @@ extern "C" {
 
 int32_t nerf_abi_version(void) { return NERF_ABI_VERSION; }
 const char* nerf_last_error(void) { return g_err; }
-int64_t nerf_packed_model_floats(void) { return nerf::kPackedFloats; }
+int64_t nerf_packed_model_bytes(int32_t precision) {
+  if (precision == NERF_PREC_F32) return nerf::kPackedFloats * (int64_t)sizeof(float);
+  if (precision == NERF_PREC_F16) return nerf::kF16PackedBytes;
+  return -1;
+}
 
-int32_t nerf_pack_model(const float* const params[24], float* packed, void* stream) {
+int32_t nerf_pack_model(const float* const params[24], void* packed, int32_t precision, void* stream) {
   if (!params || !packed) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_pack_model: null argument");
   PackArgs a;
   for (int i = 0; i < nerf::P_COUNT; ++i) {
     if (!params[i]) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_pack_model: null parameter pointer");
     a.p[i] = params[i];
   }
-  a.out = packed;
+  a.out = (float*)packed;
   const int threads = 256;
+  if (precision == NERF_PREC_F16) {
+    const long long n = nerf::kF16ConstBytes / 4 + (long long)nerf::kF16Frags * 512;
+    hipLaunchKernelGGL(nerf_pack_f16_kernel, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0, (hipStream_t)stream, a);
+    return check_launch("nerf_pack_f16_kernel");
+  }
+  if (precision != NERF_PREC_F32) return fail(NERF_ERR_UNSUPPORTED, "%s", "nerf_pack_model: unknown precision");
   const unsigned blocks = (unsigned)((nerf::kPackedFloats + threads - 1) / threads);
   hipLaunchKernelGGL(nerf_pack_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, a);
   return check_launch("nerf_pack_kernel");
@@ -275,25 +362,25 @@ int32_t nerf_positional_encoding(const float* x, int64_t n, int32_t n_freqs, flo
 }
 
 int32_t nerf_mlp_forward(const float* pts, const float* viewdirs, int64_t n_rays, int32_t n_samples,
-                         const float* packed, float* raw, int32_t precision, void* stream) {
+                         const void* packed, float* raw, int32_t precision, void* stream) {
   if (n_rays < 0 || n_samples <= 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward: bad size");
   if (n_rays == 0) return NERF_OK;
   if (!pts || !viewdirs || !packed || !raw) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward: null argument");
   MlpArgs a{};
   a.pts = pts; a.viewdirs = viewdirs; a.n_points = n_rays * n_samples; a.n_samples = n_samples;
-  a.packed = packed; a.raw = raw;
+  a.packed = (const float*)packed; a.raw = raw;
   return launch_mlp(a, false, precision, (hipStream_t)stream);
 }
 
 int32_t nerf_mlp_forward_rays(const float* rays_o, const float* rays_d, const float* tvals,
                               int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
-                              const float* packed, float* raw, int32_t precision, void* stream) {
+                              const void* packed, float* raw, int32_t precision, void* stream) {
   if (n_rays < 0 || n_samples <= 0 || t_ray_stride < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_rays: bad size");
   if (n_rays == 0) return NERF_OK;
   if (!rays_o || !rays_d || !tvals || !packed || !raw) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_rays: null argument");
   MlpArgs a{};
   a.rays_o = rays_o; a.rays_d = rays_d; a.tvals = tvals; a.t_ray_stride = t_ray_stride;
-  a.n_points = n_rays * n_samples; a.n_samples = n_samples; a.packed = packed; a.raw = raw;
+  a.n_points = n_rays * n_samples; a.n_samples = n_samples; a.packed = (const float*)packed; a.raw = raw;
   return launch_mlp(a, true, precision, (hipStream_t)stream);
 }
 
@@ -329,7 +416,7 @@ int64_t nerf_render_workspace_bytes(int64_t n_rays, int32_t n_importance) {
 }
 
 int32_t nerf_render_forward(const float* rays_o, const float* rays_d, int64_t n_rays,
-                            const float* packed_coarse, const float* packed_fine,
+                            const void* packed_coarse, const void* packed_fine,
                             const float* t_coarse, const float* u, int32_t n_importance,
                             int32_t white_bkgd, int32_t precision, void* workspace,
                             int64_t workspace_bytes, float* rgb, float* depth, void* stream) {

@@ -72,6 +72,38 @@ constexpr int64_t kOffWRgb = kOffWAlpha + 256;                 // [3][2][64]
 constexpr int64_t kOffHeadBias = kOffWRgb + 384;               // b_rgb[3], b_alpha
 constexpr int64_t kPackedFloats = kOffHeadBias + 4;
 
+// ---- fp16-activation path (nerf_mlp_f16.hip.inc): v_mfma_f32_32x32x16_f16 ---------------------
+// Same idea, K-step = 16 features: after bias+ReLU the 16 accumulator registers of out-tile m are
+// converted pairwise to fp16 and registers 8*s2 .. 8*s2+7 become, unchanged, the 8-element B
+// fragment of k-step 2m+s2; lane-half h, element j of k-step s is feature
+//     act16_feat(s,j,h) = 16s + (j&3) + 8(j>>2) + 4h.
+// A fragment of (out-tile m, k-step s): lane l=(i,h), element j = W[32m+i][act16_feat(s,j,h)] as fp16,
+// 1 KiB per fragment.  Fragments are streamed m-outer / k-inner (the order consumed) in 32-KiB
+// chunks through a 4-slot LDS ring shared by the 8 waves of a workgroup.
+NERF_HD constexpr int act16_feat(int s, int j, int h) { return 16 * s + (j & 3) + 8 * (j >> 2) + 4 * h; }
+
+constexpr int kF16ConstBytes = 16384;          // fp32 biases (same [layer][h][..] layout as the f32 stream tail)
+constexpr int kF16FragBytes = 1024;
+constexpr int kF16ChunkFrags = 32;
+constexpr int kF16ChunkBytes = kF16ChunkFrags * kF16FragBytes;
+// fragment ranges of the stream
+constexpr int kF16FragL0 = 0;                    // 8 m x 4 PE k-steps
+constexpr int kF16FragL1 = 32;                   // L1..L4: 8 m x 16
+constexpr int kF16FragL5 = kF16FragL1 + 4 * 128; // 8 m x (4 PE + 16 hidden) = 160
+constexpr int kF16FragL6 = kF16FragL5 + 160;     // L6, L7
+constexpr int kF16FragFeat = kF16FragL6 + 2 * 128;
+constexpr int kF16FragSigma = kF16FragFeat + 128;  // 1 m (row 0) x 16
+constexpr int kF16FragViews = kF16FragSigma + 16;  // 4 m x (16 feature + 2 dir)
+constexpr int kF16FragRgb = kF16FragViews + 72;    // 1 m (rows 0..2) x 8
+constexpr int kF16Frags = kF16FragRgb + 8;         // 1184 = 37 chunks exactly
+constexpr int kF16Chunks = kF16Frags / kF16ChunkFrags;
+static_assert(kF16Frags % kF16ChunkFrags == 0, "stream must be whole chunks");
+constexpr int64_t kF16PackedBytes = kF16ConstBytes + (int64_t)kF16Frags * kF16FragBytes;
+// offsets (floats) inside the const region
+constexpr int kF16OffBias = 0;                   // 9 x [2][128]
+constexpr int kF16OffBiasViews = 9 * 256;        // [2][64]
+constexpr int kF16OffHeadBias = kF16OffBiasViews + 128;   // b_rgb[3], b_alpha
+
 // Order of the 24 parameter tensors of one sub-model (reference state_dict order, network.py:22-47)
 enum ParamIdx {
   P_W0 = 0, P_B0 = 1,           // pts_linears.i -> 2i, 2i+1

@@ -88,7 +88,8 @@ class Network(nn.Module):
 
     # ---- packed weight stream (csrc/nerf_layout.h) -------------------------------------------
     def packed(self, model=""):
-        """Device tensor with the kernel's weight stream of the coarse ("") or fine model; repacked
+        """Device byte tensor with the kernel's weight stream (for self.precision: "f32" exact fp32 MFMA,
+        "f16" fp16 activations / fp32 accumulate) of the coarse ("") or fine model; repacked
         on the device whenever a parameter's storage or version changed (load_state_dict, .to(),
         optimizer.step())."""
         tag = "fine" if model == "fine" else ""
@@ -98,16 +99,17 @@ class Network(nn.Module):
         if dev.type != "cuda":
             raise _lib.NerfLibraryError("Network parameters are on the CPU: call .cuda() first; the render path is "
                                         "HIP-only (no CPU fallback)")
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        prec = _lib.PRECISIONS[self.precision]
+        key = (prec,) + tuple((p.data_ptr(), p._version) for p in params)
         hit = self._packed.get(tag)
         if hit is not None and hit[0] == key:
             return hit[1]
         lib = _lib.load()
-        out = torch.empty(_lib.packed_model_floats(), dtype=torch.float32, device=dev)
+        out = torch.empty(_lib.packed_model_bytes(prec), dtype=torch.uint8, device=dev)
         srcs = [p.detach().contiguous() for p in params]
         arr = (ctypes.c_void_p * 24)(*[_lib.ptr(t) for t in srcs])
         with torch.cuda.device(dev):
-            _lib.check(lib.nerf_pack_model(arr, out.data_ptr(), _lib.stream_of(dev)), "nerf_pack_model")
+            _lib.check(lib.nerf_pack_model(arr, out.data_ptr(), prec, _lib.stream_of(dev)), "nerf_pack_model")
         self._packed[tag] = (key, out)
         return out
 
@@ -127,7 +129,7 @@ class Network(nn.Module):
             dirs = viewdirs.detach().to(torch.float32).contiguous()
             raw = torch.empty((n, s, 4), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
-                _lib.check(lib.nerf_mlp_forward(_lib.ptr(pts), _lib.ptr(dirs), n, s, _lib.ptr(packed),
+                _lib.check(lib.nerf_mlp_forward(_lib.ptr(pts), _lib.ptr(dirs), n, s, packed.data_ptr(),
                                                 _lib.ptr(raw), prec, _lib.stream_of(dev)), "nerf_mlp_forward")
             return raw
         # ESS/ERT path (network.py:207-214, :238-253): run only the valid points, zeros elsewhere
@@ -137,7 +139,7 @@ class Network(nn.Module):
         m = pts.shape[0]
         raw_valid = torch.empty((m, 1, 4), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(lib.nerf_mlp_forward(_lib.ptr(pts), _lib.ptr(dirs), m, 1, _lib.ptr(packed),
+            _lib.check(lib.nerf_mlp_forward(_lib.ptr(pts), _lib.ptr(dirs), m, 1, packed.data_ptr(),
                                             _lib.ptr(raw_valid), prec, _lib.stream_of(dev)), "nerf_mlp_forward")
         out = torch.zeros((n * s, 4), dtype=torch.float32, device=dev)
         out[flat] = raw_valid.reshape(m, 4)

@@ -92,7 +92,8 @@ class Renderer:
         prec = _lib.PRECISIONS[getattr(self.net, "precision", "f32")]
         with torch.cuda.device(dev):
             _lib.check(lib.nerf_render_forward(
-                _lib.ptr(o), _lib.ptr(d), n, _lib.ptr(pk_c), _lib.ptr(pk_f), _lib.ptr(t_c), _lib.ptr(u),
+                _lib.ptr(o), _lib.ptr(d), n, pk_c.data_ptr(), pk_f.data_ptr() if pk_f is not None else None,
+                _lib.ptr(t_c), _lib.ptr(u),
                 int(self.N_importance), int(bool(self.white_bkgd)), prec, ws.data_ptr(), ws.numel(),
                 _lib.ptr(rgb), _lib.ptr(depth), _lib.stream_of(dev)), "nerf_render_forward")
         return rgb, depth

@@ -79,3 +79,79 @@ def pack_model(sd, prefix):
     parts.append(g("rgb_linear.bias"))
     parts.append(g("alpha_linear.bias"))
     return np.concatenate(parts)
+
+
+# ------------------------------------------------------------------ fp16 stream (nerf_layout.h)
+def act16_feat(s, j, h):
+    return 16 * s + (j & 3) + 8 * (j >> 2) + 4 * h
+
+
+def _frag(W, rows, colmap):
+    """One 1-KiB A fragment: lane l=(i,h), element j = W[rows[i]][colmap(j,h)] (fp16), zero if row/col < 0."""
+    f = np.zeros((64, 8), np.float16)
+    for h in range(2):
+        for j in range(8):
+            c = colmap(j, h)
+            if c < 0:
+                continue
+            for i in range(32):
+                if rows[i] >= 0:
+                    f[32 * h + i, j] = np.float16(W[rows[i], c])
+    return f.reshape(-1)
+
+
+def pack_model_f16(sd, prefix):
+    """-> (const region float32 [4096], fragment stream float16 [1184*512])."""
+    g = lambda n: sd[f"{prefix}.{n}"].detach().cpu().numpy().astype(np.float32)
+    frags = []
+    rows_of = lambda m: [32 * m + i for i in range(32)]
+    W0, W5 = g("pts_linears.0.weight"), g("pts_linears.5.weight")
+    for m in range(8):                                           # L0
+        for s in range(4):
+            frags.append(_frag(W0, rows_of(m), lambda j, h, s=s: pe_xyz_feat(8 * s + j, h)))
+    hidden = lambda W: [frags.append(_frag(W, rows_of(m), lambda j, h, s=s: act16_feat(s, j, h)))
+                        for m in range(8) for s in range(16)]
+    for i in (1, 2, 3, 4):
+        hidden(g(f"pts_linears.{i}.weight"))
+    for m in range(8):                                           # L5: 4 PE + 16 hidden k-steps per m
+        for s in range(4):
+            frags.append(_frag(W5, rows_of(m), lambda j, h, s=s: pe_xyz_feat(8 * s + j, h)))
+        for s in range(16):
+            frags.append(_frag(W5, rows_of(m), lambda j, h, s=s: 63 + act16_feat(s, j, h)))
+    for i in (6, 7):
+        hidden(g(f"pts_linears.{i}.weight"))
+    hidden(g("feature_linear.weight"))
+    Wa = g("alpha_linear.weight")
+    for s in range(16):                                          # sigma head: row 0
+        frags.append(_frag(Wa, [0] + [-1] * 31, lambda j, h, s=s: act16_feat(s, j, h)))
+    Wv = g("views_linears.0.weight")
+    for m in range(4):                                           # views: 16 feature + 2 dir k-steps
+        for s in range(16):
+            frags.append(_frag(Wv, rows_of(m), lambda j, h, s=s: act16_feat(s, j, h)))
+        for s in range(2):
+            def col(j, h, s=s):
+                c = pe_dir_feat(8 * s + j, h)
+                return -1 if c < 0 else 256 + c
+            frags.append(_frag(Wv, rows_of(m), col))
+    Wr = g("rgb_linear.weight")
+    for s in range(8):                                           # rgb head: rows 0..2
+        frags.append(_frag(Wr, [0, 1, 2] + [-1] * 29, lambda j, h, s=s: act16_feat(s, j, h)))
+    stream = np.concatenate(frags)
+    assert stream.size == 1184 * 512
+
+    const = np.zeros(4096, np.float32)
+
+    def bias_block(b, ntiles):
+        o = np.zeros((2, ntiles * 16), np.float32)
+        for h in range(2):
+            for j in range(ntiles):
+                for r in range(16):
+                    o[h, j * 16 + r] = b[act_feat(j, r, h)]
+        return o.reshape(-1)
+    for i in range(8):
+        const[i * 256:(i + 1) * 256] = bias_block(g(f"pts_linears.{i}.bias"), 8)
+    const[2048:2304] = bias_block(g("feature_linear.bias"), 8)
+    const[2304:2432] = bias_block(g("views_linears.0.bias"), 4)
+    const[2432:2435] = g("rgb_linear.bias")
+    const[2435] = g("alpha_linear.bias")[0]
+    return const, stream

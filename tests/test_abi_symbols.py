@@ -28,9 +28,13 @@ def test_library_builds_loads_and_exports():
         assert hasattr(lib, name), name
     lib.nerf_abi_version.restype = ctypes.c_int32
     assert lib.nerf_abi_version() == 1
-    lib.nerf_packed_model_floats.restype = ctypes.c_int64
-    # 2 x K=64 layers + 8 x K=256 layers + views (K=288 -> 128) + biases + heads
-    assert lib.nerf_packed_model_floats() == 2 * 64 * 256 + 8 * 256 * 256 + 288 * 128 + 9 * 256 + 128 + 256 + 384 + 4
+    lib.nerf_packed_model_bytes.restype = ctypes.c_int64
+    lib.nerf_packed_model_bytes.argtypes = [ctypes.c_int32]
+    # f32: 2 x K=64 layers + 8 x K=256 layers + views (K=288 -> 128) + biases + heads
+    assert lib.nerf_packed_model_bytes(0) == 4 * (2 * 64 * 256 + 8 * 256 * 256 + 288 * 128 + 9 * 256 + 128 + 256 + 384 + 4)
+    # f16: 16 KiB const region + 1184 A fragments of 1 KiB (37 chunks of 32)
+    assert lib.nerf_packed_model_bytes(1) == 16384 + 1184 * 1024
+    assert lib.nerf_packed_model_bytes(7) == -1
     lib.nerf_render_workspace_bytes.restype = ctypes.c_int64
     lib.nerf_render_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32]
     assert lib.nerf_render_workspace_bytes(640000, 128) == 640000 * 4864

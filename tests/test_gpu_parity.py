@@ -73,23 +73,23 @@ def test_checkpoint_layout_loads(amd, synthetic_sd):
 
 @pytest.mark.parametrize("model,prefix", [("", "model"), ("fine", "model_fine")])
 def test_pack_matches_layout_reference(net, synthetic_sd, model, prefix):
-    got = net.packed(model).cpu().numpy()
+    got = net.packed(model).view(torch.float32).cpu().numpy()
     want = pack_reference.pack_model(synthetic_sd, prefix)
     assert got.shape == want.shape
     assert np.array_equal(got, want)
 
 
 def test_repack_after_parameter_update(net):
-    before = net.packed("").clone()
+    before = net.packed("").view(torch.float32).clone()
     saved = net.model.rgb_linear.bias.detach().clone()
     with torch.no_grad():
         net.model.rgb_linear.bias.add_(1.0)
-    after = net.packed("")
+    after = net.packed("").view(torch.float32)
     assert not torch.equal(before, after)
     assert torch.equal(after[-4:-1], saved + 1.0)       # head biases sit at the end of the stream
     with torch.no_grad():
         net.model.rgb_linear.bias.copy_(saved)
-    assert torch.equal(net.packed(""), before)
+    assert torch.equal(net.packed("").view(torch.float32), before)
 
 
 def test_positional_encoding(net, golden):
@@ -145,7 +145,7 @@ def test_mlp_rays_mode_points_bit_exact(amd, net, golden):
     lib, L = amd._lib.load(), amd._lib
     o, d, t = g["rays_o"].cuda(), g["rays_d"].cuda(), g["t_sorted"].cuda().contiguous()
     raw_rays = torch.empty(256, 192, 4, device="cuda")
-    L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t), 192, 256, 192, L.ptr(net.packed("fine")),
+    L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t), 192, 256, 192, net.packed("fine").data_ptr(),
                                       L.ptr(raw_rays), 0, L.stream_of(o.device)))
     pts = (g["rays_o"][:, None, :] + g["rays_d"][:, None, :] * g["t_sorted"][:, :, None]).cuda()
     vd = (g["rays_d"] / torch.norm(g["rays_d"], dim=-1, keepdim=True)).cuda()
@@ -262,3 +262,62 @@ def test_full_frame_properties(amd, net, oracle, synthetic_sd):
     with torch.no_grad():
         ref_rgb, ref_dep = oracle.render(synthetic_sd, o[sub][None], d[sub][None])
     assert_image_close(oracle, rgb[sub], dep[sub], ref_rgb, ref_dep)
+
+
+# =============================================================================== fp16 activation path
+# BASELINE config 5: fp16 activations/weights, fp32 accumulate.  Not the parity path: the bar is
+# PSNR vs the reference render (north_star: >= 30 dB); measured ~45-60 dB, asserted >= 40 dB.
+@pytest.fixture(scope="module")
+def net16(amd, synthetic_sd):
+    n = amd.Network()
+    n.load_state_dict(synthetic_sd, strict=True)
+    n = n.cuda().eval()
+    n.precision = "f16"
+    return n
+
+
+@pytest.mark.parametrize("model,prefix", [("", "model"), ("fine", "model_fine")])
+def test_f16_pack_matches_layout_reference(net16, synthetic_sd, model, prefix):
+    got = net16.packed(model).cpu()
+    const, stream = pack_reference.pack_model_f16(synthetic_sd, prefix)
+    assert got.numel() == 16384 + 1184 * 1024
+    assert np.array_equal(got[:16384].view(torch.float32).numpy(), const)
+    assert np.array_equal(got[16384:].view(torch.float16).numpy(), stream)
+
+
+def test_f16_network_forward(net16, golden):
+    g = golden("network_forward.npz")
+    for model, key in (("", "raw_coarse"), ("fine", "raw_fine")):
+        raw = net16.forward(g["pts"].cuda(), g["viewdirs"].cuda(), None, model=model)
+        err = _chan_err(raw, g[key])
+        print(f"f16 network_forward[{model or 'coarse'}]: max rel-to-range err {err:.3e}")
+        assert err <= 2e-2
+    g = golden("mlp_layers.npz")            # ragged: 128 one-sample rays, every point its own direction
+    raw = net16.forward(g["pts"][:77, None, :].cuda().contiguous(), g["viewdirs"][:77].cuda().contiguous(), None, model="fine")
+    assert _chan_err(raw[:, 0], g["fine_out"][:77]) <= 2e-2
+
+
+def test_f16_many_tiles_match_f32_path(amd, net, net16, golden):
+    """More points than one persistent pass (stream wrap-around across tiles, ragged last tile)."""
+    g = golden("sampling.npz")
+    pts = (g["rays_o"][:, None, :] + g["rays_d"][:, None, :] * g["t_sorted"][:, :, None])
+    pts = torch.cat([pts] * 7, 0)[:1531].cuda().contiguous()            # 1531*192 = 293952 points = 1148.25 tiles
+    vd = torch.cat([g["rays_d"]] * 7, 0)[:1531].cuda().contiguous()
+    a = net.forward(pts, vd, None, model="fine")
+    b = net16.forward(pts, vd, None, model="fine")
+    err = _chan_err(b, a.cpu())
+    print(f"f16 vs f32 on 293952 points: {err:.3e}")
+    assert err <= 2e-2
+    b2 = net16.forward(pts, vd, None, model="fine")
+    assert torch.equal(b, b2)
+
+
+def test_f16_render_psnr(amd, net16, golden, oracle):
+    g = golden("render.npz")
+    for o, d, ref, refd in ((g["rays_o"], g["rays_d"], g["rgb_128"], g["depth_128"]),
+                            (g["pin_rays_o"], g["pin_rays_d"], g["pin_rgb"], g["pin_depth"])):
+        rgb, dep = _render(amd, net16, o[None], d[None])
+        psnr = oracle.psnr(rgb.cpu(), ref)
+        print(f"f16 render PSNR {psnr:.1f} dB, max|d rgb| {(rgb.cpu() - ref).abs().max():.2e}, "
+              f"max|d depth| {(dep.cpu() - refd).abs().max():.2e}")
+        assert psnr >= 40.0
