@@ -310,7 +310,10 @@ int launch_mlp(const MlpArgs& a, bool ray_mode, int precision, hipStream_t st) {
     return check_launch("nerf_mlp_f16_kernel");
   }
   const long long tiles = (a.n_points + nerf::kTilePts - 1) / nerf::kTilePts;
-  const long long blocks = (tiles + 3) / 4;
+  long long blocks = (tiles + 3) / 4;
+#if NERF_F32_PERSISTENT
+  if (blocks > num_cus()) blocks = num_cus();          // 512 registers per wave: exactly one workgroup per CU
+#endif
   if (blocks > 0x7fffffffLL) return fail(NERF_ERR_INVALID_ARG, "%s", "too many points for one launch");
   if (ray_mode) hipLaunchKernelGGL(nerf_mlp_f32_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(nerf_mlp_f32_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, a);
