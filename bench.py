@@ -147,11 +147,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 as: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         args.gpus = world
+    # rehearsal switches for a 1-GPU box (the real N>1 run is one rank per GPU over RCCL):
+    #   NERF_BENCH_SHARE_GPU=1  every rank uses cuda:0;  NERF_DIST_BACKEND=gloo  (RCCL refuses two ranks on one GPU)
+    if os.environ.get("NERF_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("NERF_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import nerf_replication_amd as pkg
     from nerf_replication_amd.dist import render_sharded, shard_bounds
