@@ -89,6 +89,20 @@ int32_t nerf_composite(const float* raw, const float* tvals, int64_t t_ray_strid
                        int32_t n_samples, int32_t white_bkgd, float* rgb, float* depth,
                        float* weights, void* stream);
 
+/* Pinhole ray generation on the device.  Replaces src/datasets/nerf/blender.py:102-127
+ * (float64 math, float32 result, unit directions): pixel id -> u = id % W, v = id / W,
+ * dirs = [(u-W/2)/f, -(v-H/2)/f, -1], rays_d = normalize(R dirs), rays_o = t.  `c2w` is a HOST array,
+ * row-major 3x4.  Pixels are pixel_begin .. pixel_begin+n_pixels-1 (row-major image order, a rank's
+ * tile) or, if `pixel_ids` (DEVICE int64 [n_pixels]) is given, that list (a training batch). */
+int32_t nerf_generate_rays(const double c2w[12], int32_t H, int32_t W, double focal, int64_t pixel_begin,
+                           int64_t n_pixels, const int64_t* pixel_ids, float* rays_o, float* rays_d, void* stream);
+
+/* Evaluator sums, src/evaluators/nerf.py: sums2[0] = sum over all values of
+ * (clip(pred,0,1) - clip(gt,0,1))^2 (:96-100), sums2[1] = sum of the evaluator's psnr_metric
+ * integrand (:23-30) whose uint8 subtraction and squaring wrap mod 256.  `sums2` is a
+ * DEVICE double[2], zeroed by the call; mean = sum / n_values, PSNR = 10 log10(peak^2 / mean). */
+int32_t nerf_image_metrics(const float* pred, const float* gt, int64_t n_values, double* sums2, void* stream);
+
 /* Bytes of scratch nerf_render_forward needs for n_rays rays. */
 int64_t nerf_render_workspace_bytes(int64_t n_rays, int32_t n_importance);
 

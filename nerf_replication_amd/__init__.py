@@ -9,6 +9,8 @@ GPU the product path raises.
 """
 from .network import NeRF, Network          # noqa: F401
 from .volume_renderer import Renderer       # noqa: F401
+from .rays import generate_rays             # noqa: F401
+from .evaluator import Evaluator            # noqa: F401
 from . import _lib                          # noqa: F401
 
-__all__ = ["NeRF", "Network", "Renderer"]
+__all__ = ["NeRF", "Network", "Renderer", "Evaluator", "generate_rays"]

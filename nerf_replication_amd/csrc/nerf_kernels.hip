@@ -287,6 +287,62 @@ void nerf_composite_kernel(const float* __restrict__ raw, const float* __restric
   depth_out[ray] = acc_d;
 }
 
+// ------------------------------------------------------------------------------------ ray generation
+// Pinhole rays of src/datasets/nerf/blender.py:102-127 in float64 like numpy, cast to float32 at the
+// end (:149-151).  One thread per pixel; removes the 15.4 MB/frame host->device copy of run.py:167-169.
+struct RayGenArgs {
+  double c2w[12];          // row-major 3x4 camera-to-world
+  double focal, cx, cy;
+  long long pixel_begin, n_pixels;
+  int W;
+  const long long* pixel_ids;   // optional explicit pixel list (training batches), else pixel_begin + i
+  float* rays_o;
+  float* rays_d;
+};
+__global__ void nerf_generate_rays_kernel(RayGenArgs a) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n_pixels) return;
+  const long long id = a.pixel_ids ? a.pixel_ids[i] : a.pixel_begin + i;
+  const double u = (double)(id % a.W), v = (double)(id / a.W);
+  const double dx = (u - a.cx) / a.focal, dy = -(v - a.cy) / a.focal, dz = -1.0;
+  double w[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) w[r] = (a.c2w[4 * r + 0] * dx + a.c2w[4 * r + 1] * dy) + a.c2w[4 * r + 2] * dz;
+  const double nrm = sqrt((w[0] * w[0] + w[1] * w[1]) + w[2] * w[2]);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    a.rays_d[i * 3 + r] = (float)(w[r] / nrm);
+    a.rays_o[i * 3 + r] = (float)a.c2w[4 * r + 3];
+  }
+}
+
+// ------------------------------------------------------------------------------------ image metrics
+// Sums for src/evaluators/nerf.py: float MSE of the clipped images (:96-100) and the evaluator's
+// psnr_metric (:23-30), whose uint8 subtraction AND squaring wrap modulo 256.
+__global__ __launch_bounds__(256)
+void nerf_image_metrics_kernel(const float* __restrict__ pred, const float* __restrict__ gt, long long n_values,
+                               double* __restrict__ out /*[2]: sum sq float, sum wrapped-u8 sq*/) {
+  double s_f = 0.0, s_u = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_values; i += (long long)gridDim.x * blockDim.x) {
+    const float p = fminf(fmaxf(pred[i], 0.0f), 1.0f), g = fminf(fmaxf(gt[i], 0.0f), 1.0f);
+    const float d = p - g;
+    s_f += (double)(d * d);
+    const unsigned pu = (unsigned)(p * 255.0f) & 0xffu, gu = (unsigned)(g * 255.0f) & 0xffu;   // astype(uint8): truncation
+    const unsigned du = (pu - gu) & 0xffu;
+    s_u += (double)((du * du) & 0xffu);
+  }
+  __shared__ double red[2][4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s_f += __shfl_xor(s_f, o); s_u += __shfl_xor(s_u, o); }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wave] = s_f; red[1][wave] = s_u; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&out[0], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    atomicAdd(&out[1], (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+  }
+}
+
 // ------------------------------------------------------------------------------------ launch helpers
 int num_cus() {
   static int cus = 0;
@@ -408,6 +464,35 @@ int32_t nerf_composite(const float* raw, const float* tvals, int64_t t_ray_strid
   hipLaunchKernelGGL(nerf_composite_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, raw, tvals,
                      (long long)t_ray_stride, (long long)n_rays, n_samples, white_bkgd, rgb, depth, weights);
   return check_launch("nerf_composite_kernel");
+}
+
+int32_t nerf_generate_rays(const double c2w[12], int32_t H, int32_t W, double focal, int64_t pixel_begin,
+                           int64_t n_pixels, const int64_t* pixel_ids, float* rays_o, float* rays_d, void* stream) {
+  if (n_pixels < 0 || H <= 0 || W <= 0 || !(focal > 0.0) || pixel_begin < 0 ||
+      (!pixel_ids && pixel_begin + n_pixels > (int64_t)H * W))
+    return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_generate_rays: bad size");
+  if (n_pixels == 0) return NERF_OK;
+  if (!c2w || !rays_o || !rays_d) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_generate_rays: null argument");
+  RayGenArgs a;
+  for (int i = 0; i < 12; ++i) a.c2w[i] = c2w[i];
+  a.focal = focal; a.cx = W / 2.0; a.cy = H / 2.0; a.pixel_begin = pixel_begin; a.n_pixels = n_pixels; a.W = W;
+  a.pixel_ids = (const long long*)pixel_ids; a.rays_o = rays_o; a.rays_d = rays_d;
+  hipLaunchKernelGGL(nerf_generate_rays_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("nerf_generate_rays_kernel");
+}
+
+int32_t nerf_image_metrics(const float* pred, const float* gt, int64_t n_values, double* sums2, void* stream) {
+  if (n_values < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_image_metrics: bad size");
+  if (!sums2) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_image_metrics: null argument");
+  if (hipMemsetAsync(sums2, 0, 2 * sizeof(double), (hipStream_t)stream) != hipSuccess)
+    return fail(NERF_ERR_HIP, "%s", "nerf_image_metrics: memset failed");
+  if (n_values == 0) return NERF_OK;
+  if (!pred || !gt) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_image_metrics: null argument");
+  long long blocks = (n_values + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(nerf_image_metrics_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pred, gt,
+                     (long long)n_values, sums2);
+  return check_launch("nerf_image_metrics_kernel");
 }
 
 int64_t nerf_render_workspace_bytes(int64_t n_rays, int32_t n_importance) {

@@ -298,3 +298,19 @@ def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
     """Float PSNR, data_range 1 (not the evaluator's uint8-wrapping variant)."""
     mse = torch.mean((a.double() - b.double()) ** 2).item()
     return 100.0 if mse < 1e-20 else 10.0 * math.log10(1.0 / mse)
+
+
+def evaluator_metrics(pred: torch.Tensor, gt: torch.Tensor):
+    """src/evaluators/nerf.py:96-100 and psnr_metric :23-30 restated with numpy semantics: float MSE of
+    the clipped images, and the PSNR the evaluator really prints -- its uint8 images are subtracted and
+    squared IN uint8, so both wrap modulo 256.  The evaluator module itself cannot be
+    imported here (cv2 / skimage absent): this row is restated from the source, not run-pinned."""
+    import numpy as np
+    p = np.clip(pred.detach().cpu().numpy().astype(np.float32), 0, 1)
+    g = np.clip(gt.detach().cpu().numpy().astype(np.float32), 0, 1)
+    mse = float(np.mean((p - g) ** 2))
+    pu = (p * 255).astype(np.uint8)
+    gu = (g * 255).astype(np.uint8)
+    mse_u8 = float(np.mean((pu - gu) ** 2))
+    psnr_printed = 100.0 if mse_u8 < 1e-10 else 10 * math.log10((255 ** 2) / mse_u8)
+    return mse, psnr_printed

@@ -321,3 +321,38 @@ def test_f16_render_psnr(amd, net16, golden, oracle):
         print(f"f16 render PSNR {psnr:.1f} dB, max|d rgb| {(rgb.cpu() - ref).abs().max():.2e}, "
               f"max|d depth| {(dep.cpu() - refd).abs().max():.2e}")
         assert psnr >= 40.0
+
+
+# =============================================================================== section 8(f) rows
+def test_generate_rays_matches_dataset_formula(amd, oracle, golden):
+    g = golden("render.npz")
+    c2w = g["pin_c2w"]
+    o, d = amd.generate_rays(c2w, 800, 800, oracle.LEGO_CAMERA_ANGLE_X, "cuda", pixel_ids=g["pin_ids"])
+    # the fixture rays were produced with the reference formula in float64 (blender.py:102-127)
+    assert torch.equal(o.cpu(), g["pin_rays_o"])
+    assert (d.cpu() - g["pin_rays_d"]).abs().max() <= 6e-8           # <= 1 ulp: matmul association may differ
+    # a contiguous tile (rank shard) of the full frame equals the same rows of the whole frame
+    full_o, full_d = oracle.pinhole_rays(800, 800, c2w)
+    o2, d2 = amd.generate_rays(c2w, 800, 800, oracle.LEGO_CAMERA_ANGLE_X, "cuda", pixel_begin=800 * 100, n_pixels=800 * 7)
+    assert (d2.cpu() - full_d[800 * 100:800 * 107]).abs().max() <= 6e-8 and torch.equal(o2.cpu(), full_o[:5600])
+    assert torch.allclose(d2.norm(dim=-1), torch.ones(5600, device="cuda"), atol=1e-6)
+    lib = amd._lib.load()
+    import ctypes
+    bad = (ctypes.c_double * 12)(*([0.0] * 12))
+    assert lib.nerf_generate_rays(bad, 800, 800, 1000.0, 639999, 2, None, None, None, None) == -1   # runs off the image
+
+
+def test_evaluator_metrics(amd, oracle):
+    gen = torch.Generator().manual_seed(5)
+    gt = torch.rand(4000, 3, generator=gen)
+    pred = (gt + 0.05 * torch.randn(4000, 3, generator=gen))          # some values leave [0,1] -> clip path
+    ev = amd.Evaluator()
+    ev.evaluate((pred.cuda(), None), {"colors": gt[None].cuda()})
+    ev.evaluate((gt.cuda(), None), {"colors": gt[None].cuda()})         # identical images -> the 100 dB branch
+    mse, psnr_printed = oracle.evaluator_metrics(pred, gt)
+    assert abs(ev.mse[0] - mse) <= 1e-9
+    assert abs(ev.psnr[0] - psnr_printed) <= 1e-6                      # incl. the uint8 wrap-around
+    assert ev.psnr[1] == 100.0 and ev.mse[1] == 0.0
+    assert abs(ev.psnr_float[0] - oracle.psnr(pred.clamp(0, 1), gt)) <= 1e-4
+    s = ev.summarize()
+    assert abs(s["psnr"] - (psnr_printed + 100.0) / 2) <= 1e-6 and s["ssim"] is None

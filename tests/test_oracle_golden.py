@@ -108,3 +108,15 @@ def test_autograd_fixture(oracle, golden, synthetic_sd):
         assert torch.allclose(v.grad, g["grad/" + k], rtol=1e-4, atol=1e-6), k
     coarse_l1 = sum(v.grad.abs().sum() for k, v in sd.items() if k.startswith("model."))
     assert coarse_l1 > 0
+
+
+def test_evaluator_uint8_wraparound(oracle):
+    """psnr_metric subtracts and squares uint8 images in uint8.  pred=0, gt=20/255:
+    (0 - 20) wraps to 236, 236**2 = 55696 wraps to 144 -> the printed PSNR is 10 log10(255^2/144),
+    not the true 10 log10(255^2/400)."""
+    import math
+    pred = torch.zeros(10, 3)
+    gt = torch.full((10, 3), 20.4 / 255.0)
+    mse, psnr_printed = oracle.evaluator_metrics(pred, gt)
+    assert abs(mse - (20.4 / 255.0) ** 2) < 1e-7
+    assert abs(psnr_printed - 10 * math.log10(255 ** 2 / 144.0)) < 1e-9
