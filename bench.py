@@ -34,23 +34,19 @@ PEAK_F16_MFMA = 2.5e15                   # dense fp16/bf16 MFMA, same table
 H = W = 800
 
 
-def make_rays(device):
-    """Blender-style pinhole rays of one 800x800 frame, generated on the device (same formula as
-    src/datasets/nerf/blender.py:102-127; float32 here -- bench input, not a parity fixture)."""
+def camera_pose_40():
+    """Blender-style camera-to-world (radius 4.0311, azimuth 40 deg, elevation 30 deg) -- the same pose
+    the parity tests render (oracle.camera_pose(40.0)); float64, host side."""
     import math
-    f = W / (2.0 * math.tan(0.6911112070083618 / 2.0))
-    v, u = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float32),
-                          torch.arange(W, device=device, dtype=torch.float32), indexing="ij")
-    dirs = torch.stack([(u - W / 2) / f, -(v - H / 2) / f, -torch.ones_like(u)], -1).reshape(-1, 3)
     th, ph, rad = math.radians(40.0), math.radians(-30.0), 4.031128874
-    rot_phi = torch.tensor([[1, 0, 0], [0, math.cos(ph), -math.sin(ph)], [0, math.sin(ph), math.cos(ph)]])
-    rot_th = torch.tensor([[math.cos(th), 0, -math.sin(th)], [0, 1, 0], [math.sin(th), 0, math.cos(th)]])
-    flip = torch.tensor([[-1.0, 0, 0], [0, 0, 1], [0, 1, 0]])
-    R = (flip @ rot_th @ rot_phi).to(device)
-    origin = R @ torch.tensor([0.0, 0.0, rad], device=device)
-    d = dirs @ R.T
-    d = d / d.norm(dim=-1, keepdim=True)
-    return origin.expand_as(d).contiguous(), d.contiguous()
+    rot_phi = torch.tensor([[1, 0, 0], [0, math.cos(ph), -math.sin(ph)], [0, math.sin(ph), math.cos(ph)]], dtype=torch.float64)
+    rot_th = torch.tensor([[math.cos(th), 0, -math.sin(th)], [0, 1, 0], [math.sin(th), 0, math.cos(th)]], dtype=torch.float64)
+    flip = torch.tensor([[-1.0, 0, 0], [0, 0, 1], [0, 1, 0]], dtype=torch.float64)
+    R = flip @ rot_th @ rot_phi
+    c2w = torch.zeros(3, 4, dtype=torch.float64)
+    c2w[:, :3] = R
+    c2w[:, 3] = R @ torch.tensor([0.0, 0.0, rad], dtype=torch.float64)
+    return c2w
 
 
 def load_weights():
@@ -77,7 +73,7 @@ def time_stages(pkg, net, ren, o, d, steps, prec=0):
         ev[0].record()
         L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t_c), 0, n, 64, pk_c.data_ptr(), L.ptr(raw_c), prec, st))
         ev[1].record()
-        L.check(lib.nerf_sample_fine(L.ptr(raw_c), L.ptr(t_c), L.ptr(u), n, L.ptr(t_sorted), None, st))
+        L.check(lib.nerf_sample_fine(L.ptr(raw_c), L.ptr(t_c), L.ptr(u), n, L.ptr(t_sorted), None, None, 0.0, 0.0, st))
         ev[2].record()
         L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t_sorted), 192, n, 192, pk_f.data_ptr(), L.ptr(raw_f), prec, st))
         ev[3].record()
@@ -172,7 +168,9 @@ def main():
     prec = pkg._lib.PRECISIONS[args.precision]
     peak = PEAK_F32_MFMA if prec == 0 else PEAK_F16_MFMA
     ren = pkg.Renderer(net)
-    o, d = make_rays(dev)
+    # the frame's rays are generated on the device by nerf_generate_rays (dataset formula,
+    # blender.py:102-127), resident in HBM before the timed region starts
+    o, d = pkg.generate_rays(camera_pose_40(), H, W, 0.6911112070083618, dev)
     n = o.shape[0]
 
     def step():

@@ -78,9 +78,14 @@ int32_t nerf_mlp_forward_rays(const float* rays_o, const float* rays_d, const fl
  * u [128] -> t_sorted [n,192] (ascending union of coarse and fine depths), optional t_fine [n,128].
  * Replaces ReLU of the coarse density (volume_renderer.py:335-338), weights_computation (:67-96),
  * fine_sample_points' deterministic branch (:126-154, :247-264) incl. its index clamp to 61, and the
- * cat + torch.sort of depths (:349-353); the sorted POINTS (:354-356) are regenerated as o + d*t. */
+ * cat + torch.sort of depths (:349-353); the sorted POINTS (:354-356) are regenerated as o + d*t.
+ * If `valid_sorted` [n,192] (uint8) is non-NULL the fast_sampling branch is evaluated too: ESS (coarse
+ * weight < weights_threshold around the sample, strict for rays with max sigma > 0.5) and ERT (coarse
+ * transmittance < ert_threshold) masks and the empty-ray test (:116-123, :132-133, :158-193), merged
+ * through the sort with the always-valid coarse samples (:359-369). */
 int32_t nerf_sample_fine(const float* raw_coarse, const float* t_coarse, const float* u,
-                         int64_t n_rays, float* t_sorted, float* t_fine, void* stream);
+                         int64_t n_rays, float* t_sorted, float* t_fine, uint8_t* valid_sorted,
+                         float weights_threshold, float ert_threshold, void* stream);
 
 /* Final activations + alpha compositing.  raw [n,S,4], t per (ray,sample) as above ->
  * rgb [n,3], depth [n], optional weights [n,S].  Replaces volume_renderer.py:414-432:
@@ -104,16 +109,19 @@ int32_t nerf_generate_rays(const double c2w[12], int32_t H, int32_t W, double fo
 int32_t nerf_image_metrics(const float* pred, const float* gt, int64_t n_values, double* sums2, void* stream);
 
 /* Bytes of scratch nerf_render_forward needs for n_rays rays. */
-int64_t nerf_render_workspace_bytes(int64_t n_rays, int32_t n_importance);
+int64_t nerf_render_workspace_bytes(int64_t n_rays, int32_t n_importance, int32_t fast_sampling);
 
 /* Renderer.render for already-flattened rays [n,3]: coarse pass, hierarchical sampling, fine pass,
  * compositing (volume_renderer.py:306-432).  n_importance is 0 (coarse only) or 128.  t_coarse [64]
  * and u [128] are the host-built torch.linspace tables (bit-sensitive).
- * Outputs rgb [n,3], depth [n]. */
+ * fast_sampling != 0 selects the ESS/ERT masked fine pass (off in every reference config):
+ * only merged samples that survive the masks go through the fine network (device-side compaction),
+ * the rest contribute raw = 0 exactly as network.py:238-253 does.  Outputs rgb [n,3], depth [n]. */
 int32_t nerf_render_forward(const float* rays_o, const float* rays_d, int64_t n_rays,
                             const void* packed_coarse, const void* packed_fine,
                             const float* t_coarse, const float* u, int32_t n_importance,
-                            int32_t white_bkgd, int32_t precision, void* workspace,
+                            int32_t white_bkgd, int32_t precision, int32_t fast_sampling,
+                            float weights_threshold, void* workspace,
                             int64_t workspace_bytes, float* rgb, float* depth, void* stream);
 
 #ifdef __cplusplus

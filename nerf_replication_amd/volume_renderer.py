@@ -47,8 +47,6 @@ class Renderer:
         if self.perturb or self.task == "train":
             raise NotImplementedError("stochastic (task=='train') sampling is unreachable from the reference's "
                                       "configs (SURVEY F2) and is not built")
-        if self.fast_sampling:
-            raise NotImplementedError("fast_sampling (ESS/ERT) is off by default (SURVEY F3) and not built yet")
 
     # host-built, bit-sensitive tables: torch.linspace on the CPU, then copied
     def _get_tables(self, dev):
@@ -87,13 +85,15 @@ class Renderer:
         depth = torch.empty((n,), dtype=torch.float32, device=dev)
         if n == 0:
             return rgb, depth
-        nbytes = int(lib.nerf_render_workspace_bytes(n, self.N_importance))
+        fast = int(bool(self.fast_sampling) and self.N_importance > 0)
+        nbytes = int(lib.nerf_render_workspace_bytes(n, self.N_importance, fast))
         ws = self._get_workspace(nbytes, dev)
         prec = _lib.PRECISIONS[getattr(self.net, "precision", "f32")]
         with torch.cuda.device(dev):
             _lib.check(lib.nerf_render_forward(
                 _lib.ptr(o), _lib.ptr(d), n, pk_c.data_ptr(), pk_f.data_ptr() if pk_f is not None else None,
                 _lib.ptr(t_c), _lib.ptr(u),
-                int(self.N_importance), int(bool(self.white_bkgd)), prec, ws.data_ptr(), ws.numel(),
+                int(self.N_importance), int(bool(self.white_bkgd)), prec, fast, float(self.weights_threshold),
+                ws.data_ptr(), ws.numel(),
                 _lib.ptr(rgb), _lib.ptr(depth), _lib.stream_of(dev)), "nerf_render_forward")
         return rgb, depth

@@ -144,6 +144,28 @@ def main():
         r2, z2 = ren.render({"rays_o": o2.reshape(2, 96, 3), "rays_d": d2.reshape(2, 96, 3)})
         npz("render_batched.npz", rays_o=o2.reshape(2, 96, 3), rays_d=d2.reshape(2, 96, 3), rgb=r2, depth=z2)
 
+    # (9) ESS/ERT masked fine pass (fast_sampling=True on the instance; off by default)
+    with torch.no_grad():
+        import io, contextlib
+        ren.fast_sampling = True
+        o, d = seeded_rays(256, 5)
+        t_c, pts_c = ren.stratified_sample_points_from_rays(o, d, N_samples=64, perturb=False)
+        vd = d / torch.norm(d, dim=-1, keepdim=True)
+        raw_c = net.forward(pts_c, vd, None, model="")
+        with contextlib.redirect_stdout(io.StringIO()):
+            pts_f, t_f, vmask = ren.fine_sample_points(torch.relu(raw_c[..., 3]), o, d, t_c, 128, 64, 0.25)
+            rgb_m, dep_m = ren.render({"rays_o": o[None], "rays_d": d[None]})
+            prgb_m, pdep_m = ren.render({"rays_o": po[None], "rays_d": pd[None]})
+            # the default threshold 0.25 masks out (almost) every fine sample; a second setting keeps some
+            ren.weights_threshold = 0.02
+            _, _, vmask2 = ren.fine_sample_points(torch.relu(raw_c[..., 3]), o, d, t_c, 128, 64, ren.weights_threshold)
+            rgb_m2, dep_m2 = ren.render({"rays_o": o[None], "rays_d": d[None]})
+            ren.weights_threshold = 0.25
+        ren.fast_sampling = False
+        npz("render_masked.npz", rays_o=o, rays_d=d, raw_coarse=raw_c, t_fine=t_f, valid_fine=vmask,
+            rgb=rgb_m, depth=dep_m, pin_rays_o=po, pin_rays_d=pd, pin_rgb=prgb_m, pin_depth=pdep_m,
+            valid_fine_thr002=vmask2, rgb_thr002=rgb_m2, depth_thr002=dep_m2)
+
     # (8) autograd fixture: MSE on fine RGB, grads of all 48 tensors for a 64-ray step
     net.train()
     o, d = seeded_rays(64, 21)

@@ -214,6 +214,31 @@ def fine_sample(sigma_c: torch.Tensor, t_c: torch.Tensor, n_importance: int = N_
     return t_f
 
 
+def fine_valid_mask(sigma_c: torch.Tensor, t_c: torch.Tensor, n_importance: int = N_IMPORTANCE,
+                    weights_threshold: float = 0.25, ert_threshold: float = 0.45) -> torch.Tensor:
+    """ESS/ERT validity of the fine samples, the `fast_sampling` branch of fine_sample_points
+    (volume_renderer.py:116-123, :132-133, :158-193): a fine sample is dropped when its CDF bin
+    neighbours carry coarse weight < weights_threshold (both neighbours for "object" rays with
+    max sigma > 0.5, either one otherwise), when the coarse transmittance at its lower bin is already
+    < ert_threshold, or when the whole ray is empty (sum sigma < 1e-3).  -> bool [N, n_importance]."""
+    n_s = t_c.shape[1]
+    empty_ray = sigma_c.sum(dim=-1) < 1e-3
+    object_ray = sigma_c.max(dim=-1).values > 0.5
+    T, w = transmittance_weights(sigma_c, t_c)
+    w, T = w[:, 1:-1], T[:, 1:-1]
+    empty_bins = w < weights_threshold
+    _, parts = fine_sample(sigma_c, t_c, n_importance, return_parts=True)
+    below, above = parts["below"], parts["above"]
+    ert_base = torch.cat([torch.zeros_like(T[:, :1], dtype=torch.bool), T < ert_threshold], dim=1)
+    ert_empty = torch.cummax(ert_base, dim=1)[0][:, 1:]
+    ert_non_valid = torch.gather(ert_empty, 1, below)
+    below_empty, above_empty = torch.gather(empty_bins, 1, below), torch.gather(empty_bins, 1, above)
+    ess_non_valid = torch.where(object_ray[:, None], below_empty & above_empty, below_empty | above_empty)
+    valid = ~(ess_non_valid | ert_non_valid)
+    valid[empty_ray] = False
+    return valid
+
+
 def composite(raw: torch.Tensor, t: torch.Tensor, white_bkgd: bool = True):
     """raw [N,S,4] pre-activation, t [N,S] -> rgb [N,3], depth [N]."""
     rgb = torch.sigmoid(raw[..., :3])
@@ -228,7 +253,8 @@ def composite(raw: torch.Tensor, t: torch.Tensor, white_bkgd: bool = True):
 
 # ----------------------------------------------------------------------------- render
 def render(sd, rays_o: torch.Tensor, rays_d: torch.Tensor, n_importance: int = N_IMPORTANCE,
-           white_bkgd: bool = True, return_parts: bool = False, chunk: int = MLP_CHUNK):
+           white_bkgd: bool = True, return_parts: bool = False, chunk: int = MLP_CHUNK,
+           fast_sampling: bool = False, weights_threshold: float = 0.25):
     """rays_o, rays_d [B,N,3] -> (rgb [B*N,3], depth [B*N]) exactly as Renderer.render does,
     including its 160000-ray x 64-sample blocking of the MLP calls."""
     rays_o = rays_o.reshape(-1, 3)
@@ -255,6 +281,11 @@ def render(sd, rays_o: torch.Tensor, rays_d: torch.Tensor, n_importance: int = N
                     for j in range(0, pts.shape[1], SAMPLE_BLOCK)]
             rows.append(torch.cat(cols, 1))
         raw = torch.cat(rows, 0)
+        if fast_sampling:      # volume_renderer.py:359-369 + network.py:238-253: masked-out samples get raw = 0
+            valid = torch.cat([torch.ones(n, N_SAMPLES, dtype=torch.bool), fine_valid_mask(sigma_c, t_c, n_importance, weights_threshold)], 1)
+            valid = torch.gather(valid, 1, order)
+            raw = raw * valid[..., None]
+            parts.update(valid_sorted=valid)
         parts.update(t_fine=t_f, t_sorted=depth, raw_fine=raw)
     rgb, dep = composite(raw, depth, white_bkgd)
     return (rgb, dep, parts) if return_parts else (rgb, dep)

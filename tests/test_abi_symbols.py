@@ -36,9 +36,10 @@ def test_library_builds_loads_and_exports():
     assert lib.nerf_packed_model_bytes(1) == 16384 + 1184 * 1024
     assert lib.nerf_packed_model_bytes(7) == -1
     lib.nerf_render_workspace_bytes.restype = ctypes.c_int64
-    lib.nerf_render_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32]
-    assert lib.nerf_render_workspace_bytes(640000, 128) == 640000 * 4864
-    assert lib.nerf_render_workspace_bytes(640000, 0) == 640000 * 1024
+    lib.nerf_render_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
+    assert lib.nerf_render_workspace_bytes(640000, 128, 0) == 640000 * 4864
+    assert lib.nerf_render_workspace_bytes(640000, 0, 0) == 640000 * 1024
+    assert lib.nerf_render_workspace_bytes(640000, 128, 1) == 640000 * (4864 + 192 + 768) + 256
 
 
 def test_product_path_has_no_cpu_fallback(synthetic_sd):

@@ -120,3 +120,21 @@ def test_evaluator_uint8_wraparound(oracle):
     mse, psnr_printed = oracle.evaluator_metrics(pred, gt)
     assert abs(mse - (20.4 / 255.0) ** 2) < 1e-7
     assert abs(psnr_printed - 10 * math.log10(255 ** 2 / 144.0)) < 1e-9
+
+
+def test_ess_ert_masked_path(oracle, golden, synthetic_sd):
+    """fast_sampling (off by default): the oracle's validity mask equals the
+    reference's bit for bit; the masked render agrees to rounding (the reference compacts the valid
+    points before its 512-point MLP chunks, so its GEMM row grouping differs from the oracle's)."""
+    g = golden("render_masked.npz")
+    sigma_c = torch.relu(g["raw_coarse"][..., 3])
+    t_c = oracle.stratified_t().expand(256, 64)
+    assert torch.equal(oracle.fine_valid_mask(sigma_c, t_c), g["valid_fine"].bool())
+    assert torch.equal(oracle.fine_valid_mask(sigma_c, t_c, weights_threshold=0.02), g["valid_fine_thr002"].bool())
+    assert 0.3 < g["valid_fine_thr002"].float().mean() < 0.9 and g["valid_fine"].float().mean() < 0.05
+    with torch.no_grad():
+        rgb, dep = oracle.render(synthetic_sd, g["rays_o"][None], g["rays_d"][None], fast_sampling=True)
+        rgb2, dep2 = oracle.render(synthetic_sd, g["rays_o"][None], g["rays_d"][None], fast_sampling=True,
+                                   weights_threshold=0.02)
+    assert (rgb - g["rgb"]).abs().max() <= 1e-6 and (dep - g["depth"]).abs().max() <= 1e-5
+    assert (rgb2 - g["rgb_thr002"]).abs().max() <= 1e-6 and (dep2 - g["depth_thr002"]).abs().max() <= 1e-5
