@@ -74,6 +74,27 @@ int32_t nerf_mlp_forward_rays(const float* rays_o, const float* rays_d, const fl
                               int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
                               const void* packed, float* raw, int32_t precision, void* stream);
 
+/* ---- training path (BASELINE config 3; fp32 only) ------------------------------------------------
+ * Forward with activation save: as nerf_mlp_forward_rays, and additionally stores, row-major per
+ * point (P = n_rays*n_samples; floats): pe [P,64] and dpe [P,32] (encodings in the reference's channel
+ * order, zero padded), h0..h7 [P,256] each (post-ReLU, network.py:55-56), feature [P,256] (:62),
+ * views [P,128] (post-ReLU, :66-67) -- in that order, nerf_train_save_floats(P) floats in total.
+ * These are the tensors autograd would keep for network.py:49-74. */
+int64_t nerf_train_save_floats(int64_t n_points);
+int32_t nerf_mlp_forward_rays_save(const float* rays_o, const float* rays_d, const float* tvals,
+                                   int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
+                                   const void* packed, float* raw, float* save, void* stream);
+
+/* Weight / bias gradient of one nn.Linear (or a column block of it): for o < n_out, i < n_in
+ *     dw[o*ldw + wc0 + i] += sum_p dz[p*ldz + zc0 + o] * hin[p*ldh + hc0 + i],   db[o] += sum_p dz[p*ldz + zc0 + o]
+ * i.e. autograd's grad_weight = grad_out^T @ input, grad_bias = grad_out.sum(0) for network.py:22-47;
+ * `dw` (and `db`, optional) accumulate with float atomics and must be zeroed by the caller; dw is in the
+ * nn.Linear [out, in] layout (ldw = in_features), so concatenated inputs (skip, view) are two calls with
+ * different wc0.  n_out, n_in <= 256. */
+int32_t nerf_wgrad(const float* dz, int64_t ldz, int32_t zc0, int32_t n_out, const float* hin, int64_t ldh,
+                   int32_t hc0, int32_t n_in, float* dw, int64_t ldw, int32_t wc0, float* db, int64_t n_points,
+                   void* stream);
+
 /* Hierarchical sampling + merge.  raw_coarse [n,64,4] (sigma = channel 3, pre-ReLU), t_coarse [64],
  * u [128] -> t_sorted [n,192] (ascending union of coarse and fine depths), optional t_fine [n,128].
  * Replaces ReLU of the coarse density (volume_renderer.py:335-338), weights_computation (:67-96),

@@ -8,6 +8,7 @@
 #include "nerf_layout.h"
 #include "nerf_mlp_f32.hip.inc"
 #include "nerf_mlp_f16.hip.inc"
+#include "nerf_wgrad_f32.hip.inc"
 
 namespace {
 
@@ -633,6 +634,47 @@ int32_t nerf_image_metrics(const float* pred, const float* gt, int64_t n_values,
   hipLaunchKernelGGL(nerf_image_metrics_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pred, gt,
                      (long long)n_values, sums2);
   return check_launch("nerf_image_metrics_kernel");
+}
+
+int32_t nerf_wgrad(const float* dz, int64_t ldz, int32_t zc0, int32_t n_out, const float* hin, int64_t ldh,
+                   int32_t hc0, int32_t n_in, float* dw, int64_t ldw, int32_t wc0, float* db, int64_t n_points,
+                   void* stream) {
+  if (n_points < 0 || n_out <= 0 || n_in <= 0 || n_out > 256 || n_in > 256) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_wgrad: bad size");
+  if (n_points == 0) return NERF_OK;
+  if (!dz || !hin || !dw) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_wgrad: null argument");
+  WgradArgs a;
+  a.dz = dz; a.ldz = ldz; a.zc0 = zc0; a.n_out = n_out; a.hin = hin; a.ldh = ldh; a.hc0 = hc0; a.n_in = n_in;
+  a.dw = dw; a.ldw = ldw; a.wc0 = wc0; a.db = db; a.n_points = n_points;
+  const int to = (n_out + 31) / 32, ti = (n_in + 31) / 32;
+  const long long pairs = (n_points + 1) / 2;
+  long long blocks = (pairs + 255) / 256;            // >= 256 point pairs per workgroup
+  if (blocks > num_cus()) blocks = num_cus();
+  if (blocks < 1) blocks = 1;
+  const dim3 grid((unsigned)blocks), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (to > 4 && ti > 4)      { a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<4, 4>), grid, blk, 0, st, a); }
+  else if (to > 4)           { a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<4, 1>), grid, blk, 0, st, a); }
+  else if (to > 1 && ti > 4) { a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<2, 4>), grid, blk, 0, st, a); }
+  else if (to > 1)           { a.osplit = 4; a.isplit = 1; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<1, 1>), grid, blk, 0, st, a); }
+  else if (ti > 4)           { a.osplit = 1; a.isplit = 4; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<1, 2>), grid, blk, 0, st, a); }
+  else                       { a.osplit = 1; a.isplit = 4; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<1, 1>), grid, blk, 0, st, a); }
+  return check_launch("nerf_wgrad_f32_kernel");
+}
+
+int64_t nerf_train_save_floats(int64_t n_points) { return n_points < 0 ? -1 : TrainSave::floats(n_points); }
+
+int32_t nerf_mlp_forward_rays_save(const float* rays_o, const float* rays_d, const float* tvals,
+                                   int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
+                                   const void* packed, float* raw, float* save, void* stream) {
+  if (n_rays < 0 || n_samples <= 0 || t_ray_stride < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_rays_save: bad size");
+  if (n_rays == 0) return NERF_OK;
+  if (!rays_o || !rays_d || !tvals || !packed || !raw || !save) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_rays_save: null argument");
+  MlpArgs a{};
+  a.rays_o = rays_o; a.rays_d = rays_d; a.tvals = tvals; a.t_ray_stride = t_ray_stride;
+  a.n_points = n_rays * n_samples; a.n_samples = n_samples; a.packed = (const float*)packed; a.raw = raw; a.save = save;
+  const long long tiles = (a.n_points + nerf::kTilePts - 1) / nerf::kTilePts;
+  hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, true>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("nerf_mlp_f32_kernel<save>");
 }
 
 int64_t nerf_render_workspace_bytes(int64_t n_rays, int32_t n_importance, int32_t fast_sampling) {
