@@ -85,6 +85,20 @@ int32_t nerf_mlp_forward_rays_save(const float* rays_o, const float* rays_d, con
                                    int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
                                    const void* packed, float* raw, float* save, void* stream);
 
+/* Backward of the MLP (network.py:49-74 under autograd) for the points of nerf_mlp_forward_rays_save.
+ * `packed_bwd` is the transposed weight stream of nerf_pack_model_bwd (nerf_packed_bwd_floats floats);
+ * `draw` [P,4] is d loss / d raw; `save` the forward's activation store; `gsave` scratch of
+ * nerf_train_grad_floats(P) floats (receives every layer's pre-activation gradient).  Adds the 24
+ * parameter gradients (state_dict order, nn.Linear layouts; the caller zeroes them) and, if `g_t` [P]
+ * is given, writes d loss / d t through the points (x = o + d t, positional encoding included) -- the
+ * path by which the coarse network is trained. */
+int64_t nerf_train_grad_floats(int64_t n_points);
+int64_t nerf_packed_bwd_floats(void);
+int32_t nerf_pack_model_bwd(const float* const params[24], float* packed_bwd, void* stream);
+int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float* tvals, int64_t t_ray_stride,
+                          int64_t n_rays, int32_t n_samples, const float* packed_bwd, const float* draw,
+                          const float* save, float* gsave, float* g_t, float* const grads[24], void* stream);
+
 /* Weight / bias gradient of one nn.Linear (or a column block of it): for o < n_out, i < n_in
  *     dw[o*ldw + wc0 + i] += sum_p dz[p*ldz + zc0 + o] * hin[p*ldh + hc0 + i],   db[o] += sum_p dz[p*ldz + zc0 + o]
  * i.e. autograd's grad_weight = grad_out^T @ input, grad_bias = grad_out.sum(0) for network.py:22-47;

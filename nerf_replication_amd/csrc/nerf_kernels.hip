@@ -9,6 +9,7 @@
 #include "nerf_mlp_f32.hip.inc"
 #include "nerf_mlp_f16.hip.inc"
 #include "nerf_wgrad_f32.hip.inc"
+#include "nerf_mlp_bwd_f32.hip.inc"
 
 namespace {
 
@@ -87,6 +88,46 @@ __global__ void nerf_pack_kernel(PackArgs a) {
   } else {
     const int rel = (int)(i - kOffHeadBias);
     v = rel < 3 ? a.p[P_BR][rel] : a.p[P_BA][0];
+  }
+  a.out[i] = v;
+}
+
+// transposed stream for the backward chain (nerf_layout.h kBwd*)
+__global__ void nerf_pack_bwd_kernel(PackArgs a) {
+  using namespace nerf;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= kBwdPackedFloats) return;
+  float v = 0.0f;
+  if (i < kBwdOffWAlpha) {
+    // which layer: (offset, ntiles, source weight, row stride, column offset, output kind)
+    long long rel; int nt; const float* W; int ld; int kind;      // kind 0: hidden out cols (+coff), 1: PE slots
+    int coff = 0;
+    if (i < kBwdOffWfT) { rel = i - kBwdOffWvT; nt = 8; W = a.p[P_WV]; ld = 283; kind = 0; }
+    else if (i < kBwdOffW7T) { rel = i - kBwdOffWfT; nt = 8; W = a.p[P_WF]; ld = 256; kind = 0; }
+    else if (i < kBwdOffW6T) { rel = i - kBwdOffW7T; nt = 8; W = a.p[14]; ld = 256; kind = 0; }
+    else if (i < kBwdOffW5bT) { rel = i - kBwdOffW6T; nt = 8; W = a.p[12]; ld = 256; kind = 0; }
+    else if (i < kBwdOffW5aT) { rel = i - kBwdOffW5bT; nt = 8; W = a.p[10]; ld = 319; kind = 0; coff = 63; }
+    else if (i < kBwdOffW4T) { rel = i - kBwdOffW5aT; nt = 2; W = a.p[10]; ld = 319; kind = 1; }
+    else if (i < kBwdOffW0T) { const long long r2 = i - kBwdOffW4T; const int li = 4 - (int)(r2 / wsize(128, 8));
+                               rel = r2 % wsize(128, 8); nt = 8; W = a.p[2 * li]; ld = 256; kind = 0; }
+    else { rel = i - kBwdOffW0T; nt = 2; W = a.p[P_W0]; ld = 63; kind = 1; }
+    const int q = (int)(rel & 3), lane = (int)((rel >> 2) & 63);
+    const long long blk = rel >> 8;
+    const int j = (int)(blk % nt), gq = (int)(blk / nt);
+    const int s = 4 * gq + q, t = s >> 4, r = s & 15, hk = lane >> 5, irow = lane & 31;
+    const int krow = act_feat(t, r, hk);             // feature of the layer's OUTPUT (the reduction index here)
+    if (kind == 0) v = W[(long long)krow * ld + coff + 32 * j + irow];
+    else {
+      const int hp = (irow >> 2) & 1, rp = (irow & 3) + 4 * (irow >> 3);      // accumulator row -> (register, half)
+      const int c = pe_xyz_feat(16 * j + rp, hp);
+      v = c < 0 ? 0.0f : W[(long long)krow * ld + c];
+    }
+  } else if (i < kBwdOffWRgb) {
+    const int rel = (int)(i - kBwdOffWAlpha), h = rel >> 7, slot = rel & 127;
+    v = a.p[P_WA][act_feat(slot >> 4, slot & 15, h)];
+  } else if (i < kBwdOffWRgb + 384) {
+    const int rel = (int)(i - kBwdOffWRgb), c = rel >> 7, h = (rel >> 6) & 1, slot = rel & 63;
+    v = a.p[P_WR][c * 128 + act_feat(slot >> 4, slot & 15, h)];
   }
   a.out[i] = v;
 }
@@ -659,6 +700,67 @@ int32_t nerf_wgrad(const float* dz, int64_t ldz, int32_t zc0, int32_t n_out, con
   else if (ti > 4)           { a.osplit = 1; a.isplit = 4; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<1, 2>), grid, blk, 0, st, a); }
   else                       { a.osplit = 1; a.isplit = 4; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<1, 1>), grid, blk, 0, st, a); }
   return check_launch("nerf_wgrad_f32_kernel");
+}
+
+int64_t nerf_train_grad_floats(int64_t n_points) { return n_points < 0 ? -1 : TrainGrad::floats(n_points); }
+int64_t nerf_packed_bwd_floats(void) { return nerf::kBwdPackedFloats; }
+
+int32_t nerf_pack_model_bwd(const float* const params[24], float* packed_bwd, void* stream) {
+  if (!params || !packed_bwd) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_pack_model_bwd: null argument");
+  PackArgs a;
+  for (int i = 0; i < nerf::P_COUNT; ++i) {
+    if (!params[i]) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_pack_model_bwd: null parameter pointer");
+    a.p[i] = params[i];
+  }
+  a.out = packed_bwd;
+  hipLaunchKernelGGL(nerf_pack_bwd_kernel, dim3((unsigned)((nerf::kBwdPackedFloats + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("nerf_pack_bwd_kernel");
+}
+
+// grads[24]: device pointers in state_dict order (nn.Linear layouts), accumulated into (caller zeroes them)
+int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float* tvals, int64_t t_ray_stride,
+                          int64_t n_rays, int32_t n_samples, const float* packed_bwd, const float* draw,
+                          const float* save, float* gsave, float* g_t, float* const grads[24], void* stream) {
+  if (n_rays < 0 || n_samples <= 0 || t_ray_stride < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_backward: bad size");
+  if (n_rays == 0) return NERF_OK;
+  if (!rays_o || !rays_d || !tvals || !packed_bwd || !draw || !save || !gsave || !grads)
+    return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_backward: null argument");
+  for (int i = 0; i < 24; ++i) if (!grads[i]) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_backward: null gradient pointer");
+  const long long P = n_rays * n_samples;
+  BwdArgs a;
+  a.rays_o = rays_o; a.rays_d = rays_d; a.tvals = tvals; a.t_ray_stride = t_ray_stride; a.n_points = P; a.n_samples = n_samples;
+  a.packed_bwd = packed_bwd; a.draw = draw; a.save = save; a.gsave = gsave; a.g_t = g_t;
+  const long long tiles = (P + nerf::kTilePts - 1) / nerf::kTilePts;
+  hipLaunchKernelGGL(nerf_mlp_bwd_f32_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  int rc = check_launch("nerf_mlp_bwd_f32_kernel");
+  if (rc) return rc;
+  // weight / bias gradients: grad_W = g_z^T @ input, grad_b = sum g_z   (network.py:22-47 layers)
+  const float* pe = save + TrainSave::off_pe(P);
+  const float* dpe = save + TrainSave::off_dpe(P);
+  auto H = [&](int l) { return save + TrainSave::off_h(P, l); };
+  auto GZ = [&](int l) { return gsave + TrainGrad::off_gz(P, l); };
+  const float* f = save + TrainSave::off_f(P);
+  const float* hv = save + TrainSave::off_hv(P);
+  const float* gzv = gsave + TrainGrad::off_gzv(P);
+  const float* gf = gsave + TrainGrad::off_gf(P);
+  using namespace nerf;
+#define WG(...) do { rc = nerf_wgrad(__VA_ARGS__, P, stream); if (rc) return rc; } while (0)
+  WG(draw, 4, 0, 3, hv, 128, 0, 128, grads[P_WR], 128, 0, grads[P_BR]);                 // rgb_linear
+  WG(draw, 4, 3, 1, H(7), 256, 0, 256, grads[P_WA], 256, 0, grads[P_BA]);               // alpha_linear
+  WG(gzv, 128, 0, 128, f, 256, 0, 256, grads[P_WV], 283, 0, grads[P_BV]);               // views_linears.0 [feature | dirs]
+  WG(gzv, 128, 0, 128, dpe, 32, 0, 27, grads[P_WV], 283, 256, nullptr);
+  WG(gf, 256, 0, 256, H(7), 256, 0, 256, grads[P_WF], 256, 0, grads[P_BF]);             // feature_linear
+  for (int l = 7; l >= 1; --l) {
+    if (l == 5) {                                                                      // skip: [pts63 | h4]
+      WG(GZ(5), 256, 0, 256, pe, 64, 0, 63, grads[10], 319, 0, grads[11]);
+      WG(GZ(5), 256, 0, 256, H(4), 256, 0, 256, grads[10], 319, 63, nullptr);
+    } else {
+      WG(GZ(l), 256, 0, 256, H(l - 1), 256, 0, 256, grads[2 * l], 256, 0, grads[2 * l + 1]);
+    }
+  }
+  WG(GZ(0), 256, 0, 256, pe, 64, 0, 63, grads[P_W0], 63, 0, grads[P_B0]);
+#undef WG
+  return NERF_OK;
 }
 
 int64_t nerf_train_save_floats(int64_t n_points) { return n_points < 0 ? -1 : TrainSave::floats(n_points); }

@@ -104,6 +104,21 @@ constexpr int kF16OffBias = 0;                   // 9 x [2][128]
 constexpr int kF16OffBiasViews = 9 * 256;        // [2][64]
 constexpr int kF16OffHeadBias = kF16OffBiasViews + 128;   // b_rgb[3], b_alpha
 
+// ---- transposed stream for the backward (data-gradient) chain, nerf_mlp_bwd_f32.hip.inc -------
+// Same block format; A fragment of (k-step over the layer's OUTPUT features, out-tile over its INPUT
+// features) = W[act_feat(k-step, lane>>5)][input feature of row (lane&31)]; consumption order:
+constexpr int64_t kBwdOffWvT = 0;                                   // Wv[:, :256]^T : 128 -> 256
+constexpr int64_t kBwdOffWfT = kBwdOffWvT + wsize(64, 8);           // Wf^T
+constexpr int64_t kBwdOffW7T = kBwdOffWfT + wsize(128, 8);
+constexpr int64_t kBwdOffW6T = kBwdOffW7T + wsize(128, 8);
+constexpr int64_t kBwdOffW5bT = kBwdOffW6T + wsize(128, 8);         // W5[:, 63:]^T
+constexpr int64_t kBwdOffW5aT = kBwdOffW5bT + wsize(128, 8);        // W5[:, :63]^T : 256 -> 64 PE slots
+constexpr int64_t kBwdOffW4T = kBwdOffW5aT + wsize(128, 2);         // W4^T .. W1^T
+constexpr int64_t kBwdOffW0T = kBwdOffW4T + 4 * wsize(128, 8);      // W0^T : 256 -> 64 PE slots
+constexpr int64_t kBwdOffWAlpha = kBwdOffW0T + wsize(128, 2);       // [2][128] as in the forward stream
+constexpr int64_t kBwdOffWRgb = kBwdOffWAlpha + 256;                // [3][2][64]
+constexpr int64_t kBwdPackedFloats = kBwdOffWRgb + 384 + 16 * 256;  // + slack the prefetch ring may read past the end
+
 // Order of the 24 parameter tensors of one sub-model (reference state_dict order, network.py:22-47)
 enum ParamIdx {
   P_W0 = 0, P_B0 = 1,           // pts_linears.i -> 2i, 2i+1
