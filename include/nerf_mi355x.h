@@ -99,6 +99,19 @@ int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float*
                           int64_t n_rays, int32_t n_samples, const float* packed_bwd, const float* draw,
                           const float* save, float* gsave, float* g_t, float* const grads[24], void* stream);
 
+/* Adjoint of nerf_composite (autograd of volume_renderer.py:414-432 with :67-96): g_rgb [n,3], g_depth [n]
+ * (nullable) -> g_raw [n,S,4] and, if given, g_t [n,S] (the direct dependence of the image on the sample
+ * depths through delta_k = t_{k+1}-t_k and the depth sum). */
+int32_t nerf_composite_backward(const float* raw, const float* tvals, int64_t t_ray_stride, int64_t n_rays,
+                                int32_t n_samples, int32_t white_bkgd, const float* g_rgb, const float* g_depth,
+                                float* g_raw, float* g_t, void* stream);
+
+/* Adjoint of nerf_sample_fine (autograd of volume_renderer.py:126-154, :247-264, :349-356): gradient of the
+ * merged depths g_t_sorted [n,192] -> g_raw_coarse [n,64,4] (channel 3 only; the reference does NOT detach
+ * the coarse weights, so the coarse network trains through the sample positions). */
+int32_t nerf_sample_fine_backward(const float* raw_coarse, const float* t_coarse, const float* u, int64_t n_rays,
+                                  const float* t_sorted, const float* g_t_sorted, float* g_raw_coarse, void* stream);
+
 /* Weight / bias gradient of one nn.Linear (or a column block of it): for o < n_out, i < n_in
  *     dw[o*ldw + wc0 + i] += sum_p dz[p*ldz + zc0 + o] * hin[p*ldh + hc0 + i],   db[o] += sum_p dz[p*ldz + zc0 + o]
  * i.e. autograd's grad_weight = grad_out^T @ input, grad_bias = grad_out.sum(0) for network.py:22-47;

@@ -460,6 +460,182 @@ void nerf_composite_staged_kernel(const float* __restrict__ raw, const float* __
   depth_out[ray] = acc_d;
 }
 
+// ------------------------------------------------------------------------------------ training: backward of compositing / sampling
+// One thread per ray, reverse sequential scans: the exact adjoint of the forward loops above
+// (autograd of volume_renderer.py:67-96 and :414-432).
+//   w_k = T_k a_k, T_k = prod_{j<k} q_j, q = clamp(1-a, 1e-10, 1), a = 1 - exp(-relu(s) delta), delta_k = t_{k+1}-t_k
+//   rgb = sum w_k sigmoid(r_k) + (1 - sum w_k) [white], depth = sum w_k t_k
+// Given g_rgb [n,3], g_depth [n] -> g_raw [n,S,4], g_t [n,S] (direct dependence through delta and depth).
+constexpr int kBwdRowPitch = 193;
+__global__ __launch_bounds__(64)
+void nerf_composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ tvals, long long t_ray_stride,
+                               long long n_rays, int S, int white_bkgd, const float* __restrict__ g_rgb,
+                               const float* __restrict__ g_depth, float* __restrict__ g_raw, float* __restrict__ g_t) {
+  __shared__ float s_T[64 * kBwdRowPitch];              // transmittance T_k of the forward sweep (S <= 192)
+  const long long ray = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= n_rays) return;
+  float* Tk_row = s_T + threadIdx.x * kBwdRowPitch;
+  const f32x4* r4 = reinterpret_cast<const f32x4*>(raw) + ray * S;
+  f32x4* g4 = reinterpret_cast<f32x4*>(g_raw) + ray * S;
+  const float* t = tvals + ray * t_ray_stride;
+  float* gt = g_t ? g_t + ray * S : nullptr;
+  const float gr = g_rgb[ray * 3 + 0], gg = g_rgb[ray * 3 + 1], gb = g_rgb[ray * 3 + 2];
+  const float gd = g_depth ? g_depth[ray] : 0.0f;
+  const float wb = white_bkgd ? 1.0f : 0.0f;
+  {
+    float T = 1.0f;
+    for (int k = 0; k < S; ++k) {
+      Tk_row[k] = T;
+      const float sig = fmaxf(r4[k].w, 0.0f);
+      const float delta = (k < S - 1) ? __fsub_rn(t[k + 1], t[k]) : 1e10f;
+      const float alpha = alpha_of(sig, delta);
+      T = __fmul_rn(T, fminf(fmaxf(__fsub_rn(1.0f, alpha), 1e-10f), 1.0f));
+    }
+  }
+  // reverse: suf = sum_{m>k} g_T_m T_m  (g_T_m = g_w_m a_m);  g_q_k = suf / q_k
+  float suf = 0.0f;
+  for (int k = S - 1; k >= 0; --k) {
+    const f32x4 v = r4[k];
+    const float sig = fmaxf(v.w, 0.0f);
+    const float tk = t[k];
+    const float delta = (k < S - 1) ? __fsub_rn(t[k + 1], tk) : 1e10f;
+    const float e = expf(__fmul_rn(-sig, delta));
+    const float alpha = __fsub_rn(1.0f, e);
+    const float om = __fsub_rn(1.0f, alpha);
+    const float q = fminf(fmaxf(om, 1e-10f), 1.0f);
+    const float Tk = Tk_row[k];
+    const float cr = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v.x)));
+    const float cg = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v.y)));
+    const float cb = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v.z)));
+    const float g_w = gr * (cr - wb) + gg * (cg - wb) + gb * (cb - wb) + gd * tk;
+    const float w = Tk * alpha;
+    float g_alpha = g_w * Tk;
+    if (om >= 1e-10f && om <= 1.0f) g_alpha -= suf / q;      // clamp passes the gradient inside its range
+    suf += g_w * alpha * Tk;                                 // g_T_k T_k joins the suffix for smaller k
+    const float g_sig = g_alpha * delta * e;
+    const float g_delta = (k < S - 1) ? g_alpha * sig * e : 0.0f;
+    f32x4 go;
+    go.x = gr * w * cr * (1.0f - cr);
+    go.y = gg * w * cg * (1.0f - cg);
+    go.z = gb * w * cb * (1.0f - cb);
+    go.w = v.w > 0.0f ? g_sig : 0.0f;
+    g4[k] = go;
+    if (gt) {
+      gt[k] = gd * w - g_delta;                              // delta_k = t_{k+1} - t_k
+      if (k < S - 1) gt[k + 1] += g_delta;
+    }
+  }
+}
+
+// Backward of hierarchical sampling (volume_renderer.py:126-154, :247-264 under autograd): gradient of the
+// merged depths w.r.t. the coarse densities (the coarse table and u are constants).  Recomputes the
+// forward quantities, then: g_t_fine -> g_cdf[below/above] -> g_pdf (reverse cumsum) -> g_(w+eps) ->
+// g_w (inner 62) -> g_sigma through T/alpha -> g_raw_coarse[..., 3] (relu mask).  One thread per ray.
+__global__ __launch_bounds__(kSampleThreads)
+void nerf_sample_bwd_kernel(const float* __restrict__ raw_c, const float* __restrict__ t_coarse,
+                            const float* __restrict__ u_tab, long long n_rays, const float* __restrict__ t_sorted,
+                            const float* __restrict__ g_tsorted, float* __restrict__ g_raw_c) {
+  constexpr int S = NERF_N_SAMPLES, F = NERF_N_IMPORTANCE, NB = S - 1;
+  __shared__ float s_tc[S];
+  __shared__ float s_u[F];
+  __shared__ float s_cdf[kSampleThreads * (NB + 2)];       // cdf, later g_cdf
+  __shared__ float s_gw[kSampleThreads * (S + 1)];         // g_cdf accumulator
+  __shared__ float s_T[kSampleThreads * (S + 1)];          // transmittance T_i of the coarse sweep
+  const int lane = threadIdx.x;
+  s_tc[lane] = t_coarse[lane];
+  s_u[lane] = u_tab[lane]; s_u[lane + 64] = u_tab[lane + 64];
+  __syncthreads();
+  const long long ray = (long long)blockIdx.x * kSampleThreads + lane;
+  if (ray >= n_rays) return;
+  const float* sig_p = raw_c + ray * (S * 4) + 3;
+  float* cdf = s_cdf + lane * (NB + 2);
+  float* gw = s_gw + lane * (S + 1);
+  float* Ti = s_T + lane * (S + 1);
+  // ---- forward recompute: w+eps, sum, cdf
+  float T = 1.0f, wsum = 0.0f;
+  for (int i = 0; i < S; ++i) {
+    Ti[i] = T;
+    const float sigma = fmaxf(sig_p[i * 4], 0.0f);
+    const float delta = (i < S - 1) ? __fsub_rn(s_tc[i + 1], s_tc[i]) : 1e10f;
+    const float alpha = alpha_of(sigma, delta);
+    const float w = __fmul_rn(T, alpha);
+    if (i >= 1 && i <= S - 2) { const float we = __fadd_rn(w, 1e-5f); cdf[i - 1] = we; wsum = __fadd_rn(wsum, we); }
+    T = __fmul_rn(T, fminf(fmaxf(__fsub_rn(1.0f, alpha), 1e-10f), 1.0f));
+    gw[i] = 0.0f;
+  }
+  {
+    float run = 0.0f, prev = cdf[0];
+    cdf[0] = 0.0f;
+    for (int m = 1; m < NB; ++m) { run = __fadd_rn(run, __fdiv_rn(prev, wsum)); prev = cdf[m]; cdf[m] = run; }
+  }
+  // ---- g_t_fine[k]: the merged position of fine sample k (coarse first on ties, as in the forward merge)
+  // and its adjoint into g_cdf; g_cdf accumulated in registers-free fashion: second LDS row would double the
+  // footprint, so accumulate into gw[] scratch indexed by cdf entry (63 <= 65 slots), then convert.
+  float* gcdf = gw;                                    // reuse: 63 entries
+  const float* gts = g_tsorted + ray * (S + F);
+  const float* ts = t_sorted + ray * (S + F);
+  int ind = 0, ic = 0;                                 // ic = coarse samples already merged before fine k
+  for (int k = 0; k < F; ++k) {
+    const float u = s_u[k];
+    while (ind < NB && cdf[ind] <= u) ++ind;
+    const int below = min(max(ind - 1, 0), S - 3), above = min(ind, S - 3);
+    const float cb = cdf[below], ca = cdf[above];
+    const float bb = __fmul_rn(0.5f, __fadd_rn(s_tc[below + 1], s_tc[below]));
+    const float ba = __fmul_rn(0.5f, __fadd_rn(s_tc[above + 1], s_tc[above]));
+    const float draw_ = __fsub_rn(ca, cb);
+    const bool live = !(draw_ < 1e-5f);
+    const float denom = live ? draw_ : 1.0f;
+    const float num = __fsub_rn(u, cb);
+    const float v = __fadd_rn(bb, __fmul_rn(__fdiv_rn(num, denom), __fsub_rn(ba, bb)));
+    while (ic < S && s_tc[ic] <= v) ++ic;              // coarse entries sorted before this fine sample
+    const float g = gts[k + ic];                       // its slot in the merged array
+    (void)ts;
+    const float g_frac = g * __fsub_rn(ba, bb);
+    // frac = (u - cb) / denom, denom = ca - cb when live
+    float g_cb = -g_frac / denom, g_ca = 0.0f;
+    if (live) { const float gden = -g_frac * num / (denom * denom); g_ca += gden; g_cb -= gden; }
+    gcdf[below] += g_cb;
+    gcdf[above] += g_ca;
+  }
+  // ---- cdf[m] = sum_{i<m} pdf_i  ->  g_pdf_i = sum_{m>i} g_cdf[m];  pdf = we / W
+  // first pass: g_pdf and sum_j g_pdf_j we_j  (we_j recomputed from cdf differences is inexact: recompute weights)
+  float acc = 0.0f;
+  for (int i = NB - 2; i >= 0; --i) { acc += gcdf[i + 1]; cdf[i] = acc; }      // cdf[i] now holds g_pdf_i (i = 0..61)
+  // recompute we_i to form the pdf backward, then the weights backward in one reverse sweep
+  float dot = 0.0f;
+  {
+    float T2 = 1.0f;
+    for (int i = 0; i < S; ++i) {
+      const float sigma = fmaxf(sig_p[i * 4], 0.0f);
+      const float delta = (i < S - 1) ? __fsub_rn(s_tc[i + 1], s_tc[i]) : 1e10f;
+      const float alpha = alpha_of(sigma, delta);
+      const float w = __fmul_rn(T2, alpha);
+      if (i >= 1 && i <= S - 2) dot += cdf[i - 1] * __fadd_rn(w, 1e-5f);
+      T2 = __fmul_rn(T2, fminf(fmaxf(__fsub_rn(1.0f, alpha), 1e-10f), 1.0f));
+    }
+    float suf = 0.0f;
+    f32x4* g4 = reinterpret_cast<f32x4*>(g_raw_c) + ray * S;
+    for (int i = S - 1; i >= 0; --i) {
+      const float s_raw = sig_p[i * 4];
+      const float sigma = fmaxf(s_raw, 0.0f);
+      const float delta = (i < S - 1) ? __fsub_rn(s_tc[i + 1], s_tc[i]) : 1e10f;
+      const float e = expf(__fmul_rn(-sigma, delta));
+      const float alpha = __fsub_rn(1.0f, e);
+      const float om = __fsub_rn(1.0f, alpha);
+      const float q = fminf(fmaxf(om, 1e-10f), 1.0f);
+      const float Tk = Ti[i];
+      const float g_w = (i >= 1 && i <= S - 2) ? (cdf[i - 1] / wsum - dot / (wsum * wsum)) : 0.0f;
+      float g_alpha = g_w * Tk;
+      const float g_q = suf / q;
+      if (om >= 1e-10f && om <= 1.0f) g_alpha -= g_q;
+      suf += g_w * alpha * Tk;
+      f32x4 go = {0.f, 0.f, 0.f, 0.f};
+      go.w = s_raw > 0.0f ? g_alpha * delta * e : 0.0f;
+      g4[i] = go;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ ray generation
 // Pinhole rays of src/datasets/nerf/blender.py:102-127 in float64 like numpy, cast to float32 at the
 // end (:149-151).  One thread per pixel; removes the 15.4 MB/frame host->device copy of run.py:167-169.
@@ -700,6 +876,28 @@ int32_t nerf_wgrad(const float* dz, int64_t ldz, int32_t zc0, int32_t n_out, con
   else if (ti > 4)           { a.osplit = 1; a.isplit = 4; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<1, 2>), grid, blk, 0, st, a); }
   else                       { a.osplit = 1; a.isplit = 4; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<1, 1>), grid, blk, 0, st, a); }
   return check_launch("nerf_wgrad_f32_kernel");
+}
+
+int32_t nerf_composite_backward(const float* raw, const float* tvals, int64_t t_ray_stride, int64_t n_rays,
+                                int32_t n_samples, int32_t white_bkgd, const float* g_rgb, const float* g_depth,
+                                float* g_raw, float* g_t, void* stream) {
+  if (n_rays < 0 || n_samples <= 0 || t_ray_stride < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_composite_backward: bad size");
+  if (n_rays == 0) return NERF_OK;
+  if (!raw || !tvals || !g_rgb || !g_raw) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_composite_backward: null argument");
+  hipLaunchKernelGGL(nerf_composite_bwd_kernel, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, (hipStream_t)stream, raw, tvals,
+                     (long long)t_ray_stride, (long long)n_rays, n_samples, white_bkgd, g_rgb, g_depth, g_raw, g_t);
+  return check_launch("nerf_composite_bwd_kernel");
+}
+
+int32_t nerf_sample_fine_backward(const float* raw_coarse, const float* t_coarse, const float* u, int64_t n_rays,
+                                  const float* t_sorted, const float* g_t_sorted, float* g_raw_coarse, void* stream) {
+  if (n_rays < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_sample_fine_backward: bad size");
+  if (n_rays == 0) return NERF_OK;
+  if (!raw_coarse || !t_coarse || !u || !t_sorted || !g_t_sorted || !g_raw_coarse)
+    return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_sample_fine_backward: null argument");
+  hipLaunchKernelGGL(nerf_sample_bwd_kernel, dim3((unsigned)((n_rays + kSampleThreads - 1) / kSampleThreads)), dim3(kSampleThreads), 0,
+                     (hipStream_t)stream, raw_coarse, t_coarse, u, (long long)n_rays, t_sorted, g_t_sorted, g_raw_coarse);
+  return check_launch("nerf_sample_bwd_kernel");
 }
 
 int64_t nerf_train_grad_floats(int64_t n_points) { return n_points < 0 ? -1 : TrainGrad::floats(n_points); }

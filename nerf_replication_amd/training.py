@@ -1,0 +1,117 @@
+"""Training path (BASELINE config 3): Renderer.render under autograd, fp32.
+
+The reference trains by calling the same Renderer.render with autograd on (src/train/trainers/nerf.py:27,
+trainer.py:53-60): MSE on the fine RGB only, and -- because fine_sample_points does not detach the
+coarse weights -- the coarse network learns through the sample positions.  Here the
+forward runs the SAVE-mode fused kernels and the backward is the chain of adjoint kernels behind the
+C ABI (nerf_composite_backward, nerf_mlp_backward, nerf_sample_fine_backward); torch.autograd only
+carries the 48 parameter gradients back to the optimizer.  No ATen op computes on this path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class RenderFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, renderer, rays_o, rays_d, *params):
+        lib = _lib.load()
+        net = renderer.net
+        dev = rays_o.device
+        n = rays_o.shape[0]
+        st = _lib.stream_of(dev)
+        t_c, u = renderer._get_tables(dev)
+        S_c, S_f = _lib.N_SAMPLES, _lib.N_SAMPLES + _lib.N_IMPORTANCE
+        pk_c, pk_f = net.packed(""), net.packed("fine")
+        f32 = dict(dtype=torch.float32, device=dev)
+        raw_c = torch.empty((n, S_c, 4), **f32)
+        save_c = torch.empty(int(lib.nerf_train_save_floats(n * S_c)), **f32)
+        t_sorted = torch.empty((n, S_f), **f32)
+        raw_f = torch.empty((n, S_f, 4), **f32)
+        save_f = torch.empty(int(lib.nerf_train_save_floats(n * S_f)), **f32)
+        rgb, depth = torch.empty((n, 3), **f32), torch.empty((n,), **f32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.nerf_mlp_forward_rays_save(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t_c), 0, n, S_c,
+                                                      pk_c.data_ptr(), _lib.ptr(raw_c), _lib.ptr(save_c), st), "forward(coarse)")
+            _lib.check(lib.nerf_sample_fine(_lib.ptr(raw_c), _lib.ptr(t_c), _lib.ptr(u), n, _lib.ptr(t_sorted), None, None,
+                                            0.0, 0.0, st), "nerf_sample_fine")
+            _lib.check(lib.nerf_mlp_forward_rays_save(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t_sorted), S_f, n, S_f,
+                                                      pk_f.data_ptr(), _lib.ptr(raw_f), _lib.ptr(save_f), st), "forward(fine)")
+            _lib.check(lib.nerf_composite(_lib.ptr(raw_f), _lib.ptr(t_sorted), S_f, n, S_f, int(bool(renderer.white_bkgd)),
+                                          _lib.ptr(rgb), _lib.ptr(depth), None, st), "nerf_composite")
+        ctx.renderer = renderer
+        ctx.n = n
+        ctx.params = params
+        ctx.save_for_backward(rays_o, rays_d, raw_c, save_c, t_sorted, raw_f, save_f)
+        return rgb, depth
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth):
+        lib = _lib.load()
+        renderer, n, params = ctx.renderer, ctx.n, ctx.params
+        rays_o, rays_d, raw_c, save_c, t_sorted, raw_f, save_f = ctx.saved_tensors
+        dev = rays_o.device
+        st = _lib.stream_of(dev)
+        t_c, u = renderer._get_tables(dev)
+        S_c, S_f = _lib.N_SAMPLES, _lib.N_SAMPLES + _lib.N_IMPORTANCE
+        f32 = dict(dtype=torch.float32, device=dev)
+        g_rgb = g_rgb.contiguous().to(torch.float32)
+        g_depth = None if g_depth is None else g_depth.contiguous().to(torch.float32)
+        grads = [torch.zeros_like(p, dtype=torch.float32) for p in params]          # 24 coarse + 24 fine
+        nbwd = int(lib.nerf_packed_bwd_floats())
+        with torch.cuda.device(dev):
+            # fine pass: image -> raw_fine and depths; MLP backward; points -> depths
+            g_raw_f = torch.empty((n, S_f, 4), **f32)
+            g_t = torch.empty((n, S_f), **f32)
+            _lib.check(lib.nerf_composite_backward(_lib.ptr(raw_f), _lib.ptr(t_sorted), S_f, n, S_f,
+                                                   int(bool(renderer.white_bkgd)), _lib.ptr(g_rgb),
+                                                   None if g_depth is None else _lib.ptr(g_depth),
+                                                   _lib.ptr(g_raw_f), _lib.ptr(g_t), st), "nerf_composite_backward")
+            pk_b = torch.empty(nbwd, **f32)
+            _lib.check(lib.nerf_pack_model_bwd(_ptr_array([p.detach().contiguous() for p in params[24:]]), _lib.ptr(pk_b), st))
+            gsave = torch.empty(int(lib.nerf_train_grad_floats(n * S_f)), **f32)
+            g_t_pts = torch.empty((n, S_f), **f32)
+            _lib.check(lib.nerf_mlp_backward(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t_sorted), S_f, n, S_f,
+                                             _lib.ptr(pk_b), _lib.ptr(g_raw_f), _lib.ptr(save_f), _lib.ptr(gsave),
+                                             _lib.ptr(g_t_pts), _ptr_array(grads[24:]), st), "nerf_mlp_backward(fine)")
+            g_t.add_(g_t_pts)                     # plumbing: one elementwise add of two [n,192] buffers
+            # coarse pass: depths -> coarse density -> coarse MLP parameters
+            g_raw_c = torch.empty((n, S_c, 4), **f32)
+            _lib.check(lib.nerf_sample_fine_backward(_lib.ptr(raw_c), _lib.ptr(t_c), _lib.ptr(u), n, _lib.ptr(t_sorted),
+                                                     _lib.ptr(g_t), _lib.ptr(g_raw_c), st), "nerf_sample_fine_backward")
+            _lib.check(lib.nerf_pack_model_bwd(_ptr_array([p.detach().contiguous() for p in params[:24]]), _lib.ptr(pk_b), st))
+            gsave_c = gsave[: int(lib.nerf_train_grad_floats(n * S_c))]
+            _lib.check(lib.nerf_mlp_backward(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t_c), 0, n, S_c,
+                                             _lib.ptr(pk_b), _lib.ptr(g_raw_c), _lib.ptr(save_c), _lib.ptr(gsave_c),
+                                             None, _ptr_array(grads[:24]), st), "nerf_mlp_backward(coarse)")
+        return (None, None, None) + tuple(g.to(p.dtype) for g, p in zip(grads, params))
+
+
+def render_with_grad(renderer, rays_o, rays_d):
+    """rays [n,3] (contiguous fp32, on the GPU) -> (rgb [n,3], depth [n]) attached to the autograd graph of
+    the 48 network parameters (coarse sub-model first, then fine, state_dict order)."""
+    net = renderer.net
+    if getattr(net, "precision", "f32") != "f32":
+        raise NotImplementedError("training runs on the exact fp32 path")
+    if renderer.N_importance != _lib.N_IMPORTANCE or renderer.fast_sampling:
+        raise NotImplementedError("training path is built for N_importance=128 without fast_sampling")
+    params = tuple(net.model.ordered_params()) + tuple(net.model_fine.ordered_params())
+    return RenderFunction.apply(renderer, rays_o, rays_d, *params)
+
+
+def train_step(renderer, optimizer, rays_o, rays_d, colors, clip_value=40.0):
+    """One step of the reference's intended loop (trainer.py:53-60 with trainers/nerf.py:27-33): render,
+    MSE on the fine RGB, backward, clip_grad_value_(40), optimizer.step().  Returns the loss tensor."""
+    optimizer.zero_grad(set_to_none=True)
+    rgb, _ = renderer.render({"rays_o": rays_o[None], "rays_d": rays_d[None]})
+    loss = torch.nn.functional.mse_loss(rgb, colors)
+    loss.backward()
+    torch.nn.utils.clip_grad_value_(renderer.net.parameters(), clip_value)
+    optimizer.step()
+    return loss.detach()

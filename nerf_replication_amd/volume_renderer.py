@@ -76,8 +76,15 @@ class Renderer:
         d = rays_d.detach().reshape(n, 3).to(torch.float32).contiguous()
         if torch.is_grad_enabled() and getattr(self.net, "training", False) and \
                 any(p.requires_grad for p in self.net.parameters()):
-            raise NotImplementedError("backward through the HIP renderer is not built yet: render under "
-                                      "torch.no_grad() or net.eval()")
+            # training call (trainers/nerf.py:27 under trainer.py:53-60): forward with activation save,
+            # backward through the adjoint HIP kernels (training.py)
+            if __package__ in (None, ""):
+                from nerf_replication_amd.training import render_with_grad
+            else:
+                from .training import render_with_grad
+            if n == 0:
+                return torch.empty((0, 3), device=dev), torch.empty((0,), device=dev)
+            return render_with_grad(self, o, d)
         t_c, u = self._get_tables(dev)
         pk_c = self.net.packed("")
         pk_f = self.net.packed("fine") if self.N_importance > 0 else None
