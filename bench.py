@@ -125,12 +125,52 @@ def cpu_baseline(sd, n_sample, budget_s=20.0):
                       f"(os.cpu_count()={os.cpu_count()})"}, (ids, rgb, dep)
 
 
+def train_bench(pkg, sd, dev, args, world, rank):
+    """BASELINE config 3: 4096 rays per iteration (4 x 1024 random pixels), forward with activation save,
+    backward through the adjoint kernels, clip 40, Adam lr 5e-4 -- the reference's intended step
+    (SURVEY F9).  One "step" = one iteration; value = rays/s of training."""
+    from nerf_replication_amd.training import train_step
+    n_rays = 4096
+    net = pkg.Network()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).train()
+    ren = pkg.Renderer(net)
+    ids = torch.randperm(H * W, generator=torch.Generator().manual_seed(rank))[:n_rays].to(dev)
+    o, d = pkg.generate_rays(camera_pose_40(), H, W, 0.6911112070083618, dev, pixel_ids=ids)
+    colors = torch.rand(n_rays, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4, eps=1e-8)
+    for _ in range(args.warmup):
+        train_step(ren, opt, o, d, colors)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step(ren, opt, o, d, colors)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = elapsed / args.steps * 1e3
+    flop = n_rays * POINTS_PER_RAY * FLOP_PER_POINT * 3.0          # fwd + data-grad + weight-grad
+    if rank == 0:
+        print(json.dumps({"metric": "rays/sec (training, 4096 rays/iter, 64+128, fwd+bwd+Adam)",
+                          "value": round(n_rays * world / (ms * 1e-3), 1), "unit": "rays/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic",
+                          "config": {"workload": "BASELINE.json configs[2]: 4096 rays/iter, MSE on fine RGB, clip 40, Adam 5e-4; "
+                                                 "independent replicas (no gradient all-reduce yet)"},
+                          "roofline": {"bound": "mfma", "achieved": round(flop / (ms * 1e-3) / 1e12, 2), "peak": 157.3,
+                                       "unit": "TFLOP/s", "frac": round(flop / (ms * 1e-3) / PEAK_F32_MFMA, 4), "traffic": None},
+                          "final_loss": round(loss.item(), 6)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=8192, help="rays in the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--mode", default="render", choices=["render", "train"],
+                    help="render (default: the headline 800x800 frame) or train (BASELINE config 3: 4096 rays/iter, "
+                         "fused fwd+bwd HIP MLP + Adam; prints its own JSON line)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
                     help="f32 (default, the reference's dtype: exact fp32 MFMA) or f16 (BASELINE config 5: fp16 "
                          "activations, fp32 accumulate)")
@@ -161,6 +201,8 @@ def main():
     from nerf_replication_amd.dist import render_sharded, shard_bounds
     pkg._lib.load()                                   # fail loudly without the HIP extension
     sd = load_weights()
+    if args.mode == "train":
+        return train_bench(pkg, sd, dev, args, world, rank)
     net = pkg.Network()
     net.load_state_dict(sd, strict=True)
     net = net.to(dev).eval()

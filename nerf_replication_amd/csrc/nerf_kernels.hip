@@ -869,7 +869,13 @@ int32_t nerf_wgrad(const float* dz, int64_t ldz, int32_t zc0, int32_t n_out, con
   if (blocks < 1) blocks = 1;
   const dim3 grid((unsigned)blocks), blk(256);
   hipStream_t st = (hipStream_t)stream;
-  if (to > 4 && ti > 4)      { a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<4, 4>), grid, blk, 0, st, a); }
+  const bool aligned = ldz % 4 == 0 && ldh % 4 == 0 && zc0 % 4 == 0 && hc0 % 4 == 0 &&
+                       (uintptr_t)dz % 16 == 0 && (uintptr_t)hin % 16 == 0;
+  if (n_out == 256 && n_in == 256 && aligned) {
+    a.osplit = 2; a.isplit = 2;
+    hipLaunchKernelGGL(nerf_wgrad256_f32_kernel, grid, blk, 0, st, a);
+  }
+  else if (to > 4 && ti > 4) { a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<4, 4>), grid, blk, 0, st, a); }
   else if (to > 4)           { a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<4, 1>), grid, blk, 0, st, a); }
   else if (to > 1 && ti > 4) { a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<2, 4>), grid, blk, 0, st, a); }
   else if (to > 1)           { a.osplit = 4; a.isplit = 1; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<1, 1>), grid, blk, 0, st, a); }

@@ -52,14 +52,16 @@ def test_forward_save_matches_reference_activations(amd, net, golden):
         assert _rel(raw[:, 0], g[f"{tag}_out"]) <= 2e-5
 
 
+@pytest.mark.parametrize("aligned", [False, True])
 @pytest.mark.parametrize("n_out,n_in,P", [(256, 256, 4099), (256, 63, 777), (128, 256, 1000), (128, 27, 333),
-                                           (3, 128, 2050), (1, 256, 513), (256, 256, 1)])
-def test_wgrad_gemm(amd, n_out, n_in, P):
+                                           (3, 128, 2050), (1, 256, 513), (256, 256, 1), (256, 256, 200001)])
+def test_wgrad_gemm(amd, n_out, n_in, P, aligned):
     """grad_weight = grad_out^T @ input and grad_bias = grad_out.sum(0), written into a column block of an
     nn.Linear-shaped [out, in_total] gradient (the skip / view concatenations are column blocks)."""
     lib, L = amd._lib.load(), amd._lib
     gen = torch.Generator().manual_seed(n_out * 1000 + n_in)
-    ldz, zc0, ldh, hc0, ldw, wc0 = n_out + 5, 2, n_in + 9, 4, n_in + 11, 7
+    # aligned: leading dimensions / offsets that allow the float4 fast path of the 256x256 layers
+    ldz, zc0, ldh, hc0, ldw, wc0 = (n_out + 8, 4, n_in + 12, 8, n_in + 11, 7) if aligned else (n_out + 5, 2, n_in + 9, 4, n_in + 11, 7)
     dz = torch.randn(P, ldz, generator=gen)
     hin = torch.randn(P, ldh, generator=gen)
     dw = torch.zeros(n_out, ldw, device="cuda")
