@@ -105,13 +105,16 @@ def render_with_grad(renderer, rays_o, rays_d):
     return RenderFunction.apply(renderer, rays_o, rays_d, *params)
 
 
-def train_step(renderer, optimizer, rays_o, rays_d, colors, clip_value=40.0):
+def train_step(renderer, optimizer, rays_o, rays_d, colors, clip_value=40.0, group=None):
     """One step of the reference's intended loop (trainer.py:53-60 with trainers/nerf.py:27-33): render,
-    MSE on the fine RGB, backward, clip_grad_value_(40), optimizer.step().  Returns the loss tensor."""
+    MSE on the fine RGB, backward, [data-parallel: one gradient all-reduce], clip_grad_value_(40),
+    optimizer.step().  Returns the loss tensor."""
+    from .dist import allreduce_gradients
     optimizer.zero_grad(set_to_none=True)
     rgb, _ = renderer.render({"rays_o": rays_o[None], "rays_d": rays_d[None]})
     loss = torch.nn.functional.mse_loss(rgb, colors)
     loss.backward()
+    allreduce_gradients(renderer.net.parameters(), group)
     torch.nn.utils.clip_grad_value_(renderer.net.parameters(), clip_value)
     optimizer.step()
     return loss.detach()

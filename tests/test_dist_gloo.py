@@ -78,3 +78,31 @@ def test_shard_bounds_cover_every_ray_once():
             for a, b in zip(spans, spans[1:]):
                 assert a[1] == b[0]
             assert all(hi - lo <= per for lo, hi, per in spans)
+
+
+def _grad_worker(rank, world, port, out_dir):
+    import sys
+    for p in (REPO,):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nerf_replication_amd.dist import allreduce_gradients
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.zeros(s)) for s in ((256, 63), (256,), (3, 128), (1,))]
+        for i, p in enumerate(params):
+            p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+        params.append(torch.nn.Parameter(torch.zeros(5)))            # no gradient: skipped
+        allreduce_gradients(params)
+        torch.save([p.grad for p in params[:-1]], os.path.join(out_dir, f"g{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_averages_over_ranks(tmp_path):
+    port = _free_port()
+    mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        grads = torch.load(os.path.join(tmp_path, f"g{r}.pt"))
+        for i, g in enumerate(grads):
+            assert torch.all(g == 1.5 * (i + 1))                     # mean of (1, 2) * (i + 1)
