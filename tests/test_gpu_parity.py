@@ -419,3 +419,23 @@ def test_render_masked_golden(amd, net, net16, golden, oracle):
     with torch.no_grad():
         rgb16, _ = r16.render({"rays_o": g["rays_o"][None].cuda(), "rays_d": g["rays_d"][None].cuda()})
     assert oracle.psnr(rgb16.cpu(), g["rgb_thr002"]) >= 40.0
+
+
+def test_config5_size_1600x1600_f16(amd, net16, oracle, synthetic_sd):
+    """BASELINE config 5 size on one GPU: 1600x1600 = 2 560 000 rays (491 M fine points, 12.5 GB of
+    workspace), fp16 activations.  Size-independent checks + the CPU oracle on a random subset."""
+    c2w = oracle.camera_pose(115.0)
+    o, d = amd.generate_rays(c2w, 1600, 1600, oracle.LEGO_CAMERA_ANGLE_X, "cuda")
+    assert o.shape == (2560000, 3)
+    rgb, dep = _render(amd, net16, o[None], d[None])
+    assert torch.isfinite(rgb).all() and torch.isfinite(dep).all()
+    assert rgb.min() >= -1e-3 and rgb.max() <= 1.0 + 1e-3 and dep.min() >= 0 and dep.max() <= 6.01
+    idx = torch.randperm(2560000, generator=torch.Generator().manual_seed(3))[:384]
+    with torch.no_grad():
+        ref_rgb, _ = oracle.render(synthetic_sd, o[idx].cpu()[None], d[idx].cpu()[None])
+    psnr = oracle.psnr(rgb[idx.cuda()].cpu(), ref_rgb)
+    print(f"1600x1600 f16: PSNR vs oracle on 384 rays {psnr:.1f} dB")
+    assert psnr >= 40.0
+    # the last rays of the frame (tail tiles of every kernel) equal the same rays rendered alone
+    tail_rgb, tail_dep = _render(amd, net16, o[-1000:][None], d[-1000:][None])
+    assert torch.equal(tail_rgb, rgb[-1000:]) and torch.equal(tail_dep, dep[-1000:])
