@@ -129,7 +129,7 @@ def train_bench(pkg, sd, dev, args, world, rank):
     """BASELINE config 3: 4096 rays per iteration (4 x 1024 random pixels), forward with activation save,
     backward through the adjoint kernels, clip 40, Adam lr 5e-4 -- the reference's intended step
     (SURVEY F9).  One "step" = one iteration; value = rays/s of training."""
-    from nerf_replication_amd.training import train_step
+    from nerf_replication_amd.training import train_step, FusedAdam
     n_rays = 4096
     net = pkg.Network()
     net.load_state_dict(sd, strict=True)
@@ -138,7 +138,7 @@ def train_bench(pkg, sd, dev, args, world, rank):
     ids = torch.randperm(H * W, generator=torch.Generator().manual_seed(rank))[:n_rays].to(dev)
     o, d = pkg.generate_rays(camera_pose_40(), H, W, 0.6911112070083618, dev, pixel_ids=ids)
     colors = torch.rand(n_rays, 3, generator=torch.Generator().manual_seed(1)).to(dev)
-    opt = torch.optim.Adam(net.parameters(), lr=5e-4, eps=1e-8)
+    opt = FusedAdam(net.parameters(), lr=5e-4, eps=1e-8, clip_value=40.0)      # one launch: clip 40 + Adam
     for _ in range(args.warmup):
         train_step(ren, opt, o, d, colors)
     if world > 1:

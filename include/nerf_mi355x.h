@@ -112,6 +112,15 @@ int32_t nerf_composite_backward(const float* raw, const float* tvals, int64_t t_
 int32_t nerf_sample_fine_backward(const float* raw_coarse, const float* t_coarse, const float* u, int64_t n_rays,
                                   const float* t_sorted, const float* g_t_sorted, float* g_raw_coarse, void* stream);
 
+/* Fused gradient clipping + Adam over up to 48 tensors in one launch.  Replaces
+ * clip_grad_value_(parameters, 40) (src/train/trainers/trainer.py:59) followed by torch.optim.Adam.step()
+ * as configured in src/train/optimizer.py:21-24 (betas (0.9, 0.999), no amsgrad; weight decay added to the
+ * gradient).  The pointer arrays are HOST arrays of DEVICE pointers; `step` is the 1-based step count
+ * (bias corrections are computed on the host in double); clip_value <= 0 disables clipping. */
+int32_t nerf_adam_step(int32_t n_tensors, float* const params[], const float* const grads[], float* const exp_avg[],
+                       float* const exp_avg_sq[], const int64_t numel[], float lr, float beta1, float beta2, float eps,
+                       float weight_decay, float clip_value, int64_t step, void* stream);
+
 /* Weight / bias gradient of one nn.Linear (or a column block of it): for o < n_out, i < n_in
  *     dw[o*ldw + wc0 + i] += sum_p dz[p*ldz + zc0 + o] * hin[p*ldh + hc0 + i],   db[o] += sum_p dz[p*ldz + zc0 + o]
  * i.e. autograd's grad_weight = grad_out^T @ input, grad_bias = grad_out.sum(0) for network.py:22-47;

@@ -30,6 +30,9 @@ _PROTOS = {
     "nerf_composite_backward": (_c.c_int32, [_F, _F, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _F, _F, _F, _F,
                                              _c.c_void_p]),
     "nerf_sample_fine_backward": (_c.c_int32, [_F, _F, _F, _c.c_int64, _F, _F, _F, _c.c_void_p]),
+    "nerf_adam_step": (_c.c_int32, [_c.c_int32, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_void_p),
+                                    _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_int64), _c.c_float, _c.c_float, _c.c_float,
+                                    _c.c_float, _c.c_float, _c.c_float, _c.c_int64, _c.c_void_p]),
     "nerf_train_grad_floats": (_c.c_int64, [_c.c_int64]),
     "nerf_packed_bwd_floats": (_c.c_int64, []),
     "nerf_pack_model_bwd": (_c.c_int32, [_c.POINTER(_c.c_void_p), _F, _c.c_void_p]),

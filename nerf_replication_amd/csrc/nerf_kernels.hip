@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <math.h>
 
 #include "../../include/nerf_mi355x.h"
 #include "nerf_layout.h"
@@ -636,6 +637,40 @@ void nerf_sample_bwd_kernel(const float* __restrict__ raw_c, const float* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------ fused clip + Adam (section 8f-4)
+// One launch over all 48 parameter tensors: clip_grad_value_ (trainer.py:59) + torch.optim.Adam's update
+// (optimizer.py:21-24: Adam(lr, weight_decay, eps), betas (0.9, 0.999), no amsgrad) in torch's operation
+// order (lerp for exp_avg, sqrt(v)/sqrt(bc2) + eps for the denominator).
+constexpr int kAdamMaxTensors = 48;
+struct AdamArgs {
+  float* p[kAdamMaxTensors];
+  const float* g[kAdamMaxTensors];
+  float* m[kAdamMaxTensors];
+  float* v[kAdamMaxTensors];
+  long long end[kAdamMaxTensors];      // exclusive prefix ends of the flattened index space
+  int n_tensors;
+  float lr, beta1, beta2, eps, weight_decay, clip, bc1, bc2_sqrt;
+};
+__global__ __launch_bounds__(256)
+void nerf_adam_kernel(AdamArgs a) {
+  const long long total = a.end[a.n_tensors - 1];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = a.n_tensors - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (i < a.end[mid]) hi = mid; else lo = mid + 1; }
+    const long long j = i - (lo ? a.end[lo - 1] : 0);
+    float g = a.g[lo][j];
+    if (a.clip > 0.0f) g = fminf(fmaxf(g, -a.clip), a.clip);
+    const float p = a.p[lo][j];
+    if (a.weight_decay != 0.0f) g = __fadd_rn(g, __fmul_rn(a.weight_decay, p));
+    float m = a.m[lo][j], v = a.v[lo][j];
+    m = __fadd_rn(m, __fmul_rn(__fsub_rn(g, m), 1.0f - a.beta1));                       // exp_avg.lerp_(grad, 1 - beta1)
+    v = __fadd_rn(__fmul_rn(v, a.beta2), __fmul_rn(__fmul_rn(g, g), 1.0f - a.beta2));   // mul_(beta2).addcmul_(g, g, 1 - beta2)
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), a.bc2_sqrt), a.eps);
+    a.m[lo][j] = m; a.v[lo][j] = v;
+    a.p[lo][j] = __fadd_rn(p, __fmul_rn(-(a.lr / a.bc1), __fdiv_rn(m, denom)));         // addcdiv_(m, denom, value=-step_size)
+  }
+}
+
 // ------------------------------------------------------------------------------------ ray generation
 // Pinhole rays of src/datasets/nerf/blender.py:102-127 in float64 like numpy, cast to float32 at the
 // end (:149-151).  One thread per pixel; removes the 15.4 MB/frame host->device copy of run.py:167-169.
@@ -904,6 +939,28 @@ int32_t nerf_sample_fine_backward(const float* raw_coarse, const float* t_coarse
   hipLaunchKernelGGL(nerf_sample_bwd_kernel, dim3((unsigned)((n_rays + kSampleThreads - 1) / kSampleThreads)), dim3(kSampleThreads), 0,
                      (hipStream_t)stream, raw_coarse, t_coarse, u, (long long)n_rays, t_sorted, g_t_sorted, g_raw_coarse);
   return check_launch("nerf_sample_bwd_kernel");
+}
+
+int32_t nerf_adam_step(int32_t n_tensors, float* const params[], const float* const grads[], float* const exp_avg[],
+                       float* const exp_avg_sq[], const int64_t numel[], float lr, float beta1, float beta2, float eps,
+                       float weight_decay, float clip_value, int64_t step, void* stream) {
+  if (n_tensors <= 0 || n_tensors > kAdamMaxTensors || step <= 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_adam_step: bad size");
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !numel) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_adam_step: null argument");
+  AdamArgs a;
+  long long run = 0;
+  for (int i = 0; i < n_tensors; ++i) {
+    if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_adam_step: null tensor");
+    a.p[i] = params[i]; a.g[i] = grads[i]; a.m[i] = exp_avg[i]; a.v[i] = exp_avg_sq[i];
+    run += numel[i]; a.end[i] = run;
+  }
+  if (run == 0) return NERF_OK;
+  a.n_tensors = n_tensors; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.clip = clip_value;
+  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  long long blocks = (run + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(nerf_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("nerf_adam_kernel");
 }
 
 int64_t nerf_train_grad_floats(int64_t n_points) { return n_points < 0 ? -1 : TrainGrad::floats(n_points); }

@@ -105,6 +105,51 @@ def render_with_grad(renderer, rays_o, rays_d):
     return RenderFunction.apply(renderer, rays_o, rays_d, *params)
 
 
+class FusedAdam:
+    """clip_grad_value_ + Adam in one HIP launch over all parameter tensors (nerf_adam_step).  Same update
+    as torch.optim.Adam(lr, eps, weight_decay) of src/train/optimizer.py:21-24; `lr` may be changed between
+    steps (ExponentialLR of src/utils/optimizer/lr_scheduler.py:68-79: lr0 * gamma ** (epoch / decay_epochs))."""
+
+    def __init__(self, params, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_value=40.0):
+        self.params = [p for p in params if p.requires_grad]
+        if len(self.params) > 48:
+            raise ValueError("FusedAdam handles at most 48 tensors per launch")
+        self.lr, self.betas, self.eps, self.weight_decay, self.clip_value = lr, betas, eps, weight_decay, clip_value
+        self.step_count = 0
+        self.exp_avg = [torch.zeros_like(p, dtype=torch.float32) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p, dtype=torch.float32) for p in self.params]
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    @staticmethod
+    def exponential_lr(lr0, epoch, gamma=0.1, decay_epochs=500):
+        return lr0 * gamma ** (epoch / decay_epochs)
+
+    @torch.no_grad()
+    def step(self):
+        lib = _lib.load()
+        live = [(p, m, v) for p, m, v in zip(self.params, self.exp_avg, self.exp_avg_sq) if p.grad is not None]
+        if not live:
+            return
+        self.step_count += 1
+        dev = live[0][0].device
+        grads = [p.grad.contiguous() for p, _, _ in live]
+        arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        numel = (ctypes.c_int64 * len(live))(*[p.numel() for p, _, _ in live])
+        with torch.cuda.device(dev):
+            _lib.check(lib.nerf_adam_step(len(live), arr([p for p, _, _ in live]), arr(grads), arr([m for _, m, _ in live]),
+                                          arr([v for _, _, v in live]), numel, self.lr, self.betas[0], self.betas[1], self.eps,
+                                          self.weight_decay, self.clip_value, self.step_count, _lib.stream_of(dev)),
+                       "nerf_adam_step")
+        for p, _, _ in live:          # the packed weight streams are keyed on (data_ptr, _version): an in-place no-op
+            p.add_(0)                 # bumps _version so Network.packed() repacks (cache invalidation only)
+
+
 def train_step(renderer, optimizer, rays_o, rays_d, colors, clip_value=40.0, group=None):
     """One step of the reference's intended loop (trainer.py:53-60 with trainers/nerf.py:27-33): render,
     MSE on the fine RGB, backward, [data-parallel: one gradient all-reduce], clip_grad_value_(40),
@@ -115,6 +160,7 @@ def train_step(renderer, optimizer, rays_o, rays_d, colors, clip_value=40.0, gro
     loss = torch.nn.functional.mse_loss(rgb, colors)
     loss.backward()
     allreduce_gradients(renderer.net.parameters(), group)
-    torch.nn.utils.clip_grad_value_(renderer.net.parameters(), clip_value)
+    if not isinstance(optimizer, FusedAdam):          # FusedAdam clips inside its kernel
+        torch.nn.utils.clip_grad_value_(renderer.net.parameters(), clip_value)
     optimizer.step()
     return loss.detach()

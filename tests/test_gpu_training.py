@@ -245,3 +245,32 @@ def test_short_training_run_reduces_loss(amd, oracle, synthetic_sd):
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < 0.25 * losses[0]
     for b, p in zip(before, net.model_fine.pts_linears[3].parameters()):
         assert torch.equal(b, p.detach()) and p.grad is not None          # not in the optimizer: untouched, but has a gradient
+
+
+def test_fused_adam_matches_torch_adam(amd):
+    """nerf_adam_step (clip 40 + Adam) against clip_grad_value_ + torch.optim.Adam, the reference's stock
+    optimizer (optimizer.py:21-24, trainer.py:59), over several steps with a changing learning rate."""
+    from nerf_replication_amd.training import FusedAdam
+    gen = torch.Generator().manual_seed(3)
+    shapes = [(256, 63), (256,), (128, 283), (3, 128), (1,)]
+    ref = [torch.nn.Parameter(torch.randn(s, generator=gen)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref]
+    opt_ref = torch.optim.Adam(ref, lr=5e-4, eps=1e-8, weight_decay=0.0)
+    opt = FusedAdam(mine, lr=5e-4, eps=1e-8, weight_decay=0.0, clip_value=40.0)
+    for step in range(6):
+        lr = FusedAdam.exponential_lr(5e-4, epoch=step * 40)
+        for g in opt_ref.param_groups:
+            g["lr"] = lr
+        opt.lr = lr
+        for p, q in zip(ref, mine):
+            gr = torch.randn(p.shape, generator=gen) * (100.0 if step % 2 else 0.01)      # some steps need the clip
+            p.grad = gr.clone()
+            q.grad = gr.cuda()
+        torch.nn.utils.clip_grad_value_(ref, 40.0)
+        opt_ref.step()
+        v0 = mine[0]._version
+        opt.step()
+        assert mine[0]._version > v0
+    for p, q in zip(ref, mine):
+        assert (q.detach().cpu() - p.detach()).abs().max() <= 2e-6 * max(1.0, p.detach().abs().max().item())
+    assert abs(FusedAdam.exponential_lr(5e-4, 500) - 5e-5) < 1e-12
