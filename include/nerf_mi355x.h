@@ -165,6 +165,14 @@ int32_t nerf_generate_rays(const double c2w[12], int32_t H, int32_t W, double fo
  * DEVICE double[2], zeroed by the call; mean = sum / n_values, PSNR = 10 log10(peak^2 / mean). */
 int32_t nerf_image_metrics(const float* pred, const float* gt, int64_t n_values, double* sums2, void* stream);
 
+/* SSIM sum of src/evaluators/nerf.py:49-77: skimage.metrics.structural_similarity on the uint8 images
+ * (win_size 7, channel_axis 2: uniform 7x7 window, sample covariance, K1 .01, K2 .03, data_range 255).
+ * pred, gt: [H,W,3] float in [0,1] (clipped and truncated to uint8 as the evaluator does); *sum1 (DEVICE
+ * double, zeroed by the call) = sum of the SSIM map over the (H-6)x(W-6) interior and 3 channels;
+ * SSIM = sum / ((H-6)(W-6)3).  skimage is not vendored/pinned by the reference (requirements.txt): the
+ * published algorithm is restated. */
+int32_t nerf_image_ssim(const float* pred, const float* gt, int32_t H, int32_t W, double* sum1, void* stream);
+
 /* Bytes of scratch nerf_render_forward needs for n_rays rays. */
 int64_t nerf_render_workspace_bytes(int64_t n_rays, int32_t n_importance, int32_t fast_sampling);
 

@@ -48,6 +48,7 @@ _PROTOS = {
     "nerf_generate_rays": (_c.c_int32, [_c.POINTER(_c.c_double), _c.c_int32, _c.c_int32, _c.c_double, _c.c_int64,
                                         _c.c_int64, _F, _F, _F, _c.c_void_p]),
     "nerf_image_metrics": (_c.c_int32, [_F, _F, _c.c_int64, _F, _c.c_void_p]),
+    "nerf_image_ssim": (_c.c_int32, [_F, _F, _c.c_int32, _c.c_int32, _F, _c.c_void_p]),
     "nerf_render_workspace_bytes": (_c.c_int64, [_c.c_int64, _c.c_int32, _c.c_int32]),
     "nerf_render_forward": (_c.c_int32, [_F, _F, _c.c_int64, _F, _F, _F, _F, _c.c_int32, _c.c_int32,
                                          _c.c_int32, _c.c_int32, _c.c_float, _F, _c.c_int64, _F, _F, _c.c_void_p]),

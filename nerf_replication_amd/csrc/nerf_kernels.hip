@@ -727,6 +727,38 @@ void nerf_image_metrics_kernel(const float* __restrict__ pred, const float* __re
   }
 }
 
+// SSIM of src/evaluators/nerf.py:49-77: skimage.metrics.structural_similarity(pred_u8, gt_u8, win_size=7,
+// channel_axis=2) = Wang et al. with a 7x7 uniform window, sample covariance (49/48), K1 .01, K2 .03,
+// data_range 255, mean over the (H-6)x(W-6) interior and the 3 channels; float64 like skimage.
+__global__ __launch_bounds__(256)
+void nerf_ssim_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int H, int W, double* __restrict__ out) {
+  const long long n_int = (long long)(H - 6) * (W - 6) * 3;
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_int; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % 3);
+    const long long px = i / 3;
+    const int x = (int)(px % (W - 6)) + 3, y = (int)(px / (W - 6)) + 3;
+    double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+    for (int dy = -3; dy <= 3; ++dy)
+      for (int dx = -3; dx <= 3; ++dx) {
+        const long long q = ((long long)(y + dy) * W + (x + dx)) * 3 + c;
+        const double a = (double)((unsigned)(fminf(fmaxf(pred[q], 0.f), 1.f) * 255.0f) & 0xffu);
+        const double b = (double)((unsigned)(fminf(fmaxf(gt[q], 0.f), 1.f) * 255.0f) & 0xffu);
+        sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+      }
+    const double ux = sx / 49.0, uy = sy / 49.0, cn = 49.0 / 48.0;
+    const double vx = cn * (sxx / 49.0 - ux * ux), vy = cn * (syy / 49.0 - uy * uy), vxy = cn * (sxy / 49.0 - ux * uy);
+    const double C1 = (0.01 * 255.0) * (0.01 * 255.0), C2 = (0.03 * 255.0) * (0.03 * 255.0);
+    s += ((2.0 * ux * uy + C1) * (2.0 * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
 // ------------------------------------------------------------------------------------ launch helpers
 int num_cus() {
   static int cus = 0;
@@ -1038,6 +1070,17 @@ int32_t nerf_mlp_forward_rays_save(const float* rays_o, const float* rays_d, con
   const long long tiles = (a.n_points + nerf::kTilePts - 1) / nerf::kTilePts;
   hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, true>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("nerf_mlp_f32_kernel<save>");
+}
+
+int32_t nerf_image_ssim(const float* pred, const float* gt, int32_t H, int32_t W, double* sum1, void* stream) {
+  if (H < 7 || W < 7) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_image_ssim: image smaller than the 7x7 window");
+  if (!pred || !gt || !sum1) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_image_ssim: null argument");
+  if (hipMemsetAsync(sum1, 0, sizeof(double), (hipStream_t)stream) != hipSuccess)
+    return fail(NERF_ERR_HIP, "%s", "nerf_image_ssim: memset failed");
+  long long blocks = ((long long)(H - 6) * (W - 6) * 3 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(nerf_ssim_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pred, gt, H, W, sum1);
+  return check_launch("nerf_ssim_kernel");
 }
 
 int64_t nerf_render_workspace_bytes(int64_t n_rays, int32_t n_importance, int32_t fast_sampling) {

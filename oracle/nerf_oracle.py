@@ -345,3 +345,25 @@ def evaluator_metrics(pred: torch.Tensor, gt: torch.Tensor):
     mse_u8 = float(np.mean((pu - gu) ** 2))
     psnr_printed = 100.0 if mse_u8 < 1e-10 else 10 * math.log10((255 ** 2) / mse_u8)
     return mse, psnr_printed
+
+
+def evaluator_ssim(pred_hw3: torch.Tensor, gt_hw3: torch.Tensor) -> float:
+    """ssim_metric of src/evaluators/nerf.py:49-77 = skimage.metrics.structural_similarity(pred_u8, gt_u8,
+    win_size=7, channel_axis=2): uniform 7x7 filter, sample covariance, K1=.01, K2=.03, data_range 255, mean over
+    the interior cropped by 3 pixels, averaged over channels.  skimage is absent here (and unpinned by the
+    reference's requirements.txt): restated from its published algorithm with scipy's uniform_filter."""
+    import numpy as np
+    from scipy.ndimage import uniform_filter
+    p = (np.clip(pred_hw3.detach().cpu().numpy().astype(np.float32), 0, 1) * 255).astype(np.uint8).astype(np.float64)
+    g = (np.clip(gt_hw3.detach().cpu().numpy().astype(np.float32), 0, 1) * 255).astype(np.uint8).astype(np.float64)
+    vals = []
+    for c in range(3):
+        X, Y = p[..., c], g[..., c]
+        ux, uy = uniform_filter(X, size=7), uniform_filter(Y, size=7)
+        uxx, uyy, uxy = uniform_filter(X * X, size=7), uniform_filter(Y * Y, size=7), uniform_filter(X * Y, size=7)
+        cn = 49.0 / 48.0
+        vx, vy, vxy = cn * (uxx - ux * ux), cn * (uyy - uy * uy), cn * (uxy - ux * uy)
+        C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+        S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+        vals.append(S[3:-3, 3:-3].mean())
+    return float(np.mean(vals))

@@ -370,6 +370,17 @@ def test_evaluator_metrics(amd, oracle):
     assert abs(ev.psnr_float[0] - oracle.psnr(pred.clamp(0, 1), gt)) <= 1e-4
     s = ev.summarize()
     assert abs(s["psnr"] - (psnr_printed + 100.0) / 2) <= 1e-6 and s["ssim"] is None
+    # whole-image batch: SSIM of ssim_metric (7x7 uniform window on the uint8 images)
+    H, W = 37, 53
+    img = torch.rand(H, W, 3, generator=gen)
+    smooth = torch.nn.functional.avg_pool2d(img.permute(2, 0, 1)[None], 5, 1, 2)[0].permute(1, 2, 0)
+    noisy = (smooth + 0.03 * torch.randn(H, W, 3, generator=gen)).clamp(0, 1)
+    ev2 = amd.Evaluator()
+    ev2.evaluate((noisy.reshape(-1, 3).cuda(), None), {"colors": smooth.reshape(1, -1, 3).cuda(),
+                                                      "H": torch.tensor(H), "W": torch.tensor(W)})
+    ref = oracle.evaluator_ssim(noisy, smooth)
+    assert 0.3 < ref < 0.999 and abs(ev2.ssim[0] - ref) <= 1e-9
+    assert abs(amd.evaluator.image_ssim(smooth.cuda(), smooth.cuda()) - 1.0) <= 1e-12
 
 
 def test_ess_ert_mask_stage(amd, golden):
