@@ -179,9 +179,9 @@ def main():
     ap.add_argument("--mode", default="render", choices=["render", "train"],
                     help="render (default: the headline 800x800 frame) or train (BASELINE config 3: 4096 rays/iter, "
                          "fused fwd+bwd HIP MLP + Adam; prints its own JSON line)")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
-                    help="f32 (default, the reference's dtype: exact fp32 MFMA) or f16 (BASELINE config 5: fp16 "
-                         "activations, fp32 accumulate)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32x"],
+                    help="f32 (default, the reference's dtype: exact fp32 MFMA), f16 (BASELINE config 5: fp16 "
+                         "activations, fp32 accumulate) or f32x (fp32-accurate: hi/lo split operands, 3 fp16 MFMAs per product)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -216,7 +216,8 @@ def main():
     net = net.to(dev).eval()
     net.precision = args.precision
     prec = pkg._lib.PRECISIONS[args.precision]
-    peak = PEAK_F32_MFMA if prec == 0 else PEAK_F16_MFMA
+    # f32x executes 3 fp16 MFMAs per algorithmic MAC: its ceiling in ALGORITHMIC flops is a third of the fp16 peak
+    peak = {0: PEAK_F32_MFMA, 1: PEAK_F16_MFMA, 2: PEAK_F16_MFMA / 3.0}[prec]
     ren = pkg.Renderer(net)
     # the frame's rays are generated on the device by nerf_generate_rays (dataset formula,
     # blender.py:102-127), resident in HBM before the timed region starts
@@ -271,7 +272,7 @@ def main():
         out = {"metric": "rays/sec (800x800, 64+128 samples)", "value": round(value, 1), "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-               "dtype": "f32" if prec == 0 else "f16 (fp32 accumulate)",
+               "dtype": {0: "f32", 1: "f16 (fp32 accumulate)", 2: "f32 emulated (hi/lo fp16 split x3, fp32 accumulate)"}[prec],
                "data": "synthetic",
                "config": {"workload": "lego-shaped 800x800 frame = 640000 pinhole rays, 64 coarse + 128 fine "
                                       "hierarchical samples, 8+1-layer W=256 NeRF x2, seeded synthetic weights "

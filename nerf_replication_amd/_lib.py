@@ -14,7 +14,8 @@ N_SAMPLES = 64
 N_IMPORTANCE = 128
 PREC_F32 = 0
 PREC_F16 = 1
-PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "f16": PREC_F16, "fp16": PREC_F16}
+PREC_F32X = 2
+PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "f16": PREC_F16, "fp16": PREC_F16, "f32x": PREC_F32X}
 
 _c = ctypes
 _F = _c.c_void_p   # device pointers travel as integers (tensor.data_ptr())

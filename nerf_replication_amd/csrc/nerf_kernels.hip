@@ -9,6 +9,7 @@
 #include "nerf_layout.h"
 #include "nerf_mlp_f32.hip.inc"
 #include "nerf_mlp_f16.hip.inc"
+#include "nerf_mlp_f32x.hip.inc"
 #include "nerf_wgrad_f32.hip.inc"
 #include "nerf_mlp_bwd_f32.hip.inc"
 
@@ -133,31 +134,9 @@ __global__ void nerf_pack_bwd_kernel(PackArgs a) {
   a.out[i] = v;
 }
 
-// fp16 stream (nerf_layout.h "fp16-activation path"): const region (fp32 biases) + A fragments
-__global__ void nerf_pack_f16_kernel(PackArgs a) {
+// fp32 value of element (fragment F, lane, j) of the fp16 fragment stream (nerf_layout.h)
+__device__ __forceinline__ float f16_stream_value(const PackArgs& a, int F, int lane, int j) {
   using namespace nerf;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  constexpr long long n_const = kF16ConstBytes / 4;
-  constexpr long long n_half = (long long)kF16Frags * 512;
-  if (i < n_const) {                     // const region, floats
-    float v = 0.0f;
-    if (i < kF16OffBiasViews) {
-      const int rel = (int)i, layer = rel >> 8, h = (rel >> 7) & 1, slot = rel & 127;
-      const float* b = layer < 8 ? a.p[2 * layer + 1] : a.p[P_BF];
-      v = b[act_feat(slot >> 4, slot & 15, h)];
-    } else if (i < kF16OffHeadBias) {
-      const int rel = (int)i - kF16OffBiasViews, h = rel >> 6, slot = rel & 63;
-      v = a.p[P_BV][act_feat(slot >> 4, slot & 15, h)];
-    } else if (i < kF16OffHeadBias + 4) {
-      const int rel = (int)i - kF16OffHeadBias;
-      v = rel < 3 ? a.p[P_BR][rel] : a.p[P_BA][0];
-    }
-    a.out[i] = v;
-    return;
-  }
-  const long long e = i - n_const;
-  if (e >= n_half) return;
-  const int F = (int)(e >> 9), lane = (int)((e >> 3) & 63), j = (int)(e & 7);
   const int h = lane >> 5, row = lane & 31;
   const int cj = (j & 3) + 8 * (j >> 2) + 4 * h;              // act16_feat(s,j,h) - 16 s
   float v = 0.0f;
@@ -188,7 +167,43 @@ __global__ void nerf_pack_f16_kernel(PackArgs a) {
     const int s = F - kF16FragRgb;
     if (row < 3) v = a.p[P_WR][row * 128 + 16 * s + cj];
   }
-  reinterpret_cast<_Float16*>(reinterpret_cast<char*>(a.out) + kF16ConstBytes)[e] = (_Float16)v;
+  return v;
+}
+
+// fp16 stream (nerf_layout.h "fp16-activation path"): const region (fp32 biases) + A fragments; with SPLIT the
+// "f32x" stream: every fragment followed by its low-part fragment (w = w_h + 2^-11 w_l)
+template <bool SPLIT>
+__global__ void nerf_pack_f16_kernel(PackArgs a) {
+  using namespace nerf;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr long long n_const = kF16ConstBytes / 4;
+  constexpr long long n_half = (long long)kF16Frags * 512;
+  if (i < n_const) {                     // const region, floats
+    float v = 0.0f;
+    if (i < kF16OffBiasViews) {
+      const int rel = (int)i, layer = rel >> 8, h = (rel >> 7) & 1, slot = rel & 127;
+      const float* b = layer < 8 ? a.p[2 * layer + 1] : a.p[P_BF];
+      v = b[act_feat(slot >> 4, slot & 15, h)];
+    } else if (i < kF16OffHeadBias) {
+      const int rel = (int)i - kF16OffBiasViews, h = rel >> 6, slot = rel & 63;
+      v = a.p[P_BV][act_feat(slot >> 4, slot & 15, h)];
+    } else if (i < kF16OffHeadBias + 4) {
+      const int rel = (int)i - kF16OffHeadBias;
+      v = rel < 3 ? a.p[P_BR][rel] : a.p[P_BA][0];
+    }
+    a.out[i] = v;
+    return;
+  }
+  const long long e = i - n_const;
+  if (e >= n_half) return;
+  const int F = (int)(e >> 9), lane = (int)((e >> 3) & 63), j = (int)(e & 7);
+  const float v = f16_stream_value(a, F, lane, j);
+  _Float16* out = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(a.out) + kF16ConstBytes);
+  if (!SPLIT) { out[e] = (_Float16)v; return; }
+  const _Float16 hi = (_Float16)v;
+  const long long base = ((long long)(2 * F) << 9) + (e & 511);
+  out[base] = hi;
+  out[base + 512] = (_Float16)((v - (float)hi) * 2048.0f);
 }
 
 // ------------------------------------------------------------------------------------ PE (test entry)
@@ -772,8 +787,16 @@ int num_cus() {
 }
 
 int launch_mlp(const MlpArgs& a, bool ray_mode, int precision, hipStream_t st) {
-  if (precision != NERF_PREC_F32 && precision != NERF_PREC_F16) return fail(NERF_ERR_UNSUPPORTED, "%s", "precision not built");
+  if (precision != NERF_PREC_F32 && precision != NERF_PREC_F16 && precision != NERF_PREC_F32X)
+    return fail(NERF_ERR_UNSUPPORTED, "%s", "precision not built");
   if (a.n_points <= 0) return NERF_OK;
+  if (precision == NERF_PREC_F32X) {       // persistent workgroups of 4 waves, one per CU
+    const long long n_tiles = (a.n_points + kXTilePts - 1) / kXTilePts;
+    const unsigned blocks = (unsigned)(n_tiles < num_cus() ? n_tiles : num_cus());
+    if (ray_mode) hipLaunchKernelGGL(nerf_mlp_f32x_kernel<true>, dim3(blocks), dim3(kXThreads), 0, st, a);
+    else hipLaunchKernelGGL(nerf_mlp_f32x_kernel<false>, dim3(blocks), dim3(kXThreads), 0, st, a);
+    return check_launch("nerf_mlp_f32x_kernel");
+  }
   if (precision == NERF_PREC_F16) {        // persistent workgroups, one per CU (147 KB of LDS each)
     const long long n_tiles = (a.n_points + kF16TilePts - 1) / kF16TilePts;
     const unsigned blocks = (unsigned)(n_tiles < num_cus() ? n_tiles : num_cus());
@@ -804,6 +827,7 @@ const char* nerf_last_error(void) { return g_err; }
 int64_t nerf_packed_model_bytes(int32_t precision) {
   if (precision == NERF_PREC_F32) return nerf::kPackedFloats * (int64_t)sizeof(float);
   if (precision == NERF_PREC_F16) return nerf::kF16PackedBytes;
+  if (precision == NERF_PREC_F32X) return nerf::kXPackedBytes;
   return -1;
 }
 
@@ -816,9 +840,11 @@ int32_t nerf_pack_model(const float* const params[24], void* packed, int32_t pre
   }
   a.out = (float*)packed;
   const int threads = 256;
-  if (precision == NERF_PREC_F16) {
+  if (precision == NERF_PREC_F16 || precision == NERF_PREC_F32X) {
     const long long n = nerf::kF16ConstBytes / 4 + (long long)nerf::kF16Frags * 512;
-    hipLaunchKernelGGL(nerf_pack_f16_kernel, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)((n + threads - 1) / threads));
+    if (precision == NERF_PREC_F16) hipLaunchKernelGGL(nerf_pack_f16_kernel<false>, grid, dim3(threads), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(nerf_pack_f16_kernel<true>, grid, dim3(threads), 0, (hipStream_t)stream, a);
     return check_launch("nerf_pack_f16_kernel");
   }
   if (precision != NERF_PREC_F32) return fail(NERF_ERR_UNSUPPORTED, "%s", "nerf_pack_model: unknown precision");

@@ -99,6 +99,10 @@ constexpr int kF16Frags = kF16FragRgb + 8;         // 1184 = 37 chunks exactly
 constexpr int kF16Chunks = kF16Frags / kF16ChunkFrags;
 static_assert(kF16Frags % kF16ChunkFrags == 0, "stream must be whole chunks");
 constexpr int64_t kF16PackedBytes = kF16ConstBytes + (int64_t)kF16Frags * kF16FragBytes;
+// "f32x" (nerf_mlp_f32x.hip.inc): the same stream with every fragment followed by its low-part fragment
+constexpr int kXFrags = 2 * kF16Frags;                       // (hi, lo) pairs
+constexpr int kXChunks = kXFrags / kF16ChunkFrags;           // 74
+constexpr int64_t kXPackedBytes = kF16ConstBytes + (int64_t)kXFrags * kF16FragBytes;
 // offsets (floats) inside the const region
 constexpr int kF16OffBias = 0;                   // 9 x [2][128]
 constexpr int kF16OffBiasViews = 9 * 256;        // [2][64]

@@ -88,7 +88,7 @@ def act16_feat(s, j, h):
 
 def _frag(W, rows, colmap):
     """One 1-KiB A fragment: lane l=(i,h), element j = W[rows[i]][colmap(j,h)] (fp16), zero if row/col < 0."""
-    f = np.zeros((64, 8), np.float16)
+    f = np.zeros((64, 8), np.float32)
     for h in range(2):
         for j in range(8):
             c = colmap(j, h)
@@ -96,12 +96,13 @@ def _frag(W, rows, colmap):
                 continue
             for i in range(32):
                 if rows[i] >= 0:
-                    f[32 * h + i, j] = np.float16(W[rows[i], c])
+                    f[32 * h + i, j] = W[rows[i], c]
     return f.reshape(-1)
 
 
-def pack_model_f16(sd, prefix):
-    """-> (const region float32 [4096], fragment stream float16 [1184*512])."""
+def pack_model_f16(sd, prefix, split=False):
+    """-> (const region float32 [4096], fragment stream float16 [1184*512]); with split=True the "f32x"
+    stream [2368*512]: every fragment followed by its low part, w = w_h + 2^-11 w_l."""
     g = lambda n: sd[f"{prefix}.{n}"].detach().cpu().numpy().astype(np.float32)
     frags = []
     rows_of = lambda m: [32 * m + i for i in range(32)]
@@ -136,8 +137,16 @@ def pack_model_f16(sd, prefix):
     Wr = g("rgb_linear.weight")
     for s in range(8):                                           # rgb head: rows 0..2
         frags.append(_frag(Wr, [0, 1, 2] + [-1] * 29, lambda j, h, s=s: act16_feat(s, j, h)))
-    stream = np.concatenate(frags)
-    assert stream.size == 1184 * 512
+    assert len(frags) == 1184
+    if split:
+        out = []
+        for f32 in frags:
+            hi = f32.astype(np.float16)
+            lo = ((f32 - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+            out += [hi, lo]
+        stream = np.concatenate(out)
+    else:
+        stream = np.concatenate(frags).astype(np.float16)
 
     const = np.zeros(4096, np.float32)
 

@@ -450,3 +450,50 @@ def test_config5_size_1600x1600_f16(amd, net16, oracle, synthetic_sd):
     # the last rays of the frame (tail tiles of every kernel) equal the same rays rendered alone
     tail_rgb, tail_dep = _render(amd, net16, o[-1000:][None], d[-1000:][None])
     assert torch.equal(tail_rgb, rgb[-1000:]) and torch.equal(tail_dep, dep[-1000:])
+
+
+# =============================================================================== "f32x": fp32-accurate on fp16 MFMA
+# Operands split into hi + 2^-11 lo fp16 parts, 3 MFMAs per product, fp32 accumulate (nerf_mlp_f32x.hip.inc).
+# Held to the SAME tolerances as the exact-fp32 path.
+@pytest.fixture(scope="module")
+def netx(amd, synthetic_sd):
+    n = amd.Network()
+    n.load_state_dict(synthetic_sd, strict=True)
+    n = n.cuda().eval()
+    n.precision = "f32x"
+    return n
+
+
+def test_f32x_pack_matches_layout_reference(netx, synthetic_sd):
+    got = netx.packed("fine").cpu()
+    const, stream = pack_reference.pack_model_f16(synthetic_sd, "model_fine", split=True)
+    assert got.numel() == 16384 + 2368 * 1024
+    assert np.array_equal(got[:16384].view(torch.float32).numpy(), const)
+    assert np.array_equal(got[16384:].view(torch.float16).numpy(), stream)
+
+
+def test_f32x_network_forward_fp32_tolerance(netx, net, golden):
+    g = golden("network_forward.npz")
+    for model, key in (("", "raw_coarse"), ("fine", "raw_fine")):
+        raw = netx.forward(g["pts"].cuda(), g["viewdirs"].cuda(), None, model=model)
+        err = _chan_err(raw, g[key])
+        print(f"f32x network_forward[{model or 'coarse'}]: max rel-to-range err {err:.3e}")
+        assert err <= RAW_RTOL
+    g = golden("sampling.npz")                 # many tiles, ragged tail, stream wrap-around
+    pts = (g["rays_o"][:, None, :] + g["rays_d"][:, None, :] * g["t_sorted"][:, :, None])
+    pts = torch.cat([pts] * 5, 0)[:1111].cuda().contiguous()
+    vd = torch.cat([g["rays_d"]] * 5, 0)[:1111].cuda().contiguous()
+    a = net.forward(pts, vd, None, model="fine")
+    b = netx.forward(pts, vd, None, model="fine")
+    assert _chan_err(b, a.cpu()) <= RAW_RTOL
+    assert torch.equal(b, netx.forward(pts, vd, None, model="fine"))
+
+
+def test_f32x_render_golden(amd, netx, golden, oracle):
+    g = golden("render.npz")
+    rgb, dep = _render(amd, netx, g["rays_o"][None], g["rays_d"][None])
+    assert_image_close(oracle, rgb, dep, g["rgb_128"], g["depth_128"])
+    prgb, pdep = _render(amd, netx, g["pin_rays_o"][None], g["pin_rays_d"][None])
+    assert_image_close(oracle, prgb, pdep, g["pin_rgb"], g["pin_depth"])
+    rgb0, dep0 = _render(amd, netx, g["rays_o"][None], g["rays_d"][None], n_importance=0)
+    assert (rgb0.cpu() - g["rgb_0"]).abs().max() <= 2e-5 and (dep0.cpu() - g["depth_0"]).abs().max() <= 1e-4
