@@ -291,6 +291,28 @@ def main():
                 g_rgb, g_dep = ren.render({"rays_o": oo[None].to(dev), "rays_d": dd[None].to(dev)})
             out["psnr_vs_cpu_oracle_db"] = round(orc.psnr(g_rgb.cpu(), ref_rgb), 1)
             out["speedup_vs_cpu_baseline"] = round(value / base["value"], 1)
+            # informational: the other arithmetic modes of the same path on the same frame (NOT the headline value)
+            others = {}
+            for pname in ("f32x", "f16"):
+                if pname == args.precision:
+                    continue
+                net.precision = pname
+                with torch.no_grad():
+                    ren.render({"rays_o": o[None], "rays_d": d[None]})
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(3):
+                        ren.render({"rays_o": o[None], "rays_d": d[None]})
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t1) / 3
+                    p_rgb, _ = ren.render({"rays_o": oo[None].to(dev), "rays_d": dd[None].to(dev)})
+                others[pname] = {"rays_per_s": round(n / dt, 1), "ms_per_frame": round(dt * 1e3, 2),
+                                 "psnr_vs_cpu_oracle_db": round(orc.psnr(p_rgb.cpu(), ref_rgb), 1),
+                                 "arithmetic": {"f32x": "hi/lo fp16 operand split, 3 MFMAs per product, fp32 accumulate "
+                                                        "(meets the fp32 path's parity tolerances)",
+                                                "f16": "fp16 activations and weights, fp32 accumulate (config 5)"}[pname]}
+            net.precision = args.precision
+            out["other_precisions"] = others
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

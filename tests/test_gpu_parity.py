@@ -497,3 +497,21 @@ def test_f32x_render_golden(amd, netx, golden, oracle):
     assert_image_close(oracle, prgb, pdep, g["pin_rgb"], g["pin_depth"])
     rgb0, dep0 = _render(amd, netx, g["rays_o"][None], g["rays_d"][None], n_importance=0)
     assert (rgb0.cpu() - g["rgb_0"]).abs().max() <= 2e-5 and (dep0.cpu() - g["depth_0"]).abs().max() <= 1e-4
+
+
+def test_f32x_is_as_accurate_as_exact_fp32(net, netx, oracle, synthetic_sd, golden):
+    """Against a float64 evaluation of the network (the true value), the split-operand path must be in
+    the same error class as the exact-fp32 MFMA path and as PyTorch's own fp32 CPU result."""
+    g = golden("network_forward.npz")
+    sd64 = {k: v.double() for k, v in synthetic_sd.items()}
+    pts, vd = g["pts"], g["viewdirs"]
+    flat = pts.reshape(-1, 3)
+    emb = torch.cat([oracle.freq_encode(flat.double(), 10),
+                     oracle.freq_encode(vd[:, None].expand(8, 64, 3).reshape(-1, 3).double(), 4)], -1)
+    with torch.no_grad():
+        truth = oracle.nerf_mlp(sd64, "model_fine", emb).reshape(8, 64, 4)
+    e32 = _chan_err(net.forward(pts.cuda(), vd.cuda(), None, model="fine"), truth)
+    ex = _chan_err(netx.forward(pts.cuda(), vd.cuda(), None, model="fine"), truth)
+    ecpu = _chan_err(g["raw_fine"], truth)
+    print(f"error vs float64: torch-CPU fp32 {ecpu:.2e}, exact-fp32 MFMA {e32:.2e}, f32x {ex:.2e}")
+    assert ex <= 4 * max(e32, ecpu) and ex <= 1e-5
