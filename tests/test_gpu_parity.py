@@ -515,3 +515,27 @@ def test_f32x_is_as_accurate_as_exact_fp32(net, netx, oracle, synthetic_sd, gold
     ecpu = _chan_err(g["raw_fine"], truth)
     print(f"error vs float64: torch-CPU fp32 {ecpu:.2e}, exact-fp32 MFMA {e32:.2e}, f32x {ex:.2e}")
     assert ex <= 4 * max(e32, ecpu) and ex <= 1e-5
+
+
+def test_config4_second_scene_and_pose(amd, oracle):
+    """BASELINE config 4 shape on one GPU: a second scene (different seeded weights, generated live so the
+    oracle and the HIP path see the same tensors) and pose, rendered as two contiguous ray tiles the way the
+    8-GPU shard does, against the CPU oracle."""
+    from nerf_replication_amd.dist import shard_bounds
+    sd = oracle.synthetic_state_dict(seed=1, occupied=0.25)
+    net2 = amd.Network()
+    net2.load_state_dict(sd, strict=True)
+    net2 = net2.cuda().eval()
+    ren = amd.Renderer(net2)
+    ids = torch.sort(torch.randperm(800 * 800, generator=torch.Generator().manual_seed(44))[:600]).values
+    o, d = oracle.pinhole_rays(800, 800, oracle.camera_pose(200.0, -20.0), pixel_ids=ids)
+    parts = []
+    with torch.no_grad():
+        for r in range(2):
+            lo, hi, _ = shard_bounds(600, r, 2)
+            parts.append(ren.render({"rays_o": o[lo:hi][None].cuda(), "rays_d": d[lo:hi][None].cuda()}))
+        whole = ren.render({"rays_o": o[None].cuda(), "rays_d": d[None].cuda()})
+        ref_rgb, ref_dep = oracle.render(sd, o[None], d[None])
+    rgb = torch.cat([p[0] for p in parts]); dep = torch.cat([p[1] for p in parts])
+    assert torch.equal(rgb, whole[0]) and torch.equal(dep, whole[1])       # tiles == whole frame, bit for bit
+    assert_image_close(oracle, rgb, dep, ref_rgb, ref_dep)
