@@ -134,6 +134,7 @@ def train_bench(pkg, sd, dev, args, world, rank):
     net = pkg.Network()
     net.load_state_dict(sd, strict=True)
     net = net.to(dev).train()
+    net.precision = args.precision if args.precision in ("f32", "f32x") else "f32"
     ren = pkg.Renderer(net)
     ids = torch.randperm(H * W, generator=torch.Generator().manual_seed(rank))[:n_rays].to(dev)
     o, d = pkg.generate_rays(camera_pose_40(), H, W, 0.6911112070083618, dev, pixel_ids=ids)

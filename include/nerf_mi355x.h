@@ -81,11 +81,12 @@ int32_t nerf_mlp_forward_rays(const float* rays_o, const float* rays_d, const fl
  * point (P = n_rays*n_samples; floats): pe [P,64] and dpe [P,32] (encodings in the reference's channel
  * order, zero padded), h0..h7 [P,256] each (post-ReLU, network.py:55-56), feature [P,256] (:62),
  * views [P,128] (post-ReLU, :66-67) -- in that order, nerf_train_save_floats(P) floats in total.
- * These are the tensors autograd would keep for network.py:49-74. */
+ * These are the tensors autograd would keep for network.py:49-74.  precision: NERF_PREC_F32 or NERF_PREC_F32X
+ * (`packed` must be the stream of that precision); the backward kernels are fp32 either way. */
 int64_t nerf_train_save_floats(int64_t n_points);
 int32_t nerf_mlp_forward_rays_save(const float* rays_o, const float* rays_d, const float* tvals,
                                    int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
-                                   const void* packed, float* raw, float* save, void* stream);
+                                   const void* packed, float* raw, float* save, int32_t precision, void* stream);
 
 /* Backward of the MLP (network.py:49-74 under autograd) for the points of nerf_mlp_forward_rays_save.
  * `packed_bwd` is the transposed weight stream of nerf_pack_model_bwd (nerf_packed_bwd_floats floats);

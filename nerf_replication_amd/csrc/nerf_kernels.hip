@@ -1086,13 +1086,20 @@ int64_t nerf_train_save_floats(int64_t n_points) { return n_points < 0 ? -1 : Tr
 
 int32_t nerf_mlp_forward_rays_save(const float* rays_o, const float* rays_d, const float* tvals,
                                    int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
-                                   const void* packed, float* raw, float* save, void* stream) {
+                                   const void* packed, float* raw, float* save, int32_t precision, void* stream) {
   if (n_rays < 0 || n_samples <= 0 || t_ray_stride < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_rays_save: bad size");
   if (n_rays == 0) return NERF_OK;
   if (!rays_o || !rays_d || !tvals || !packed || !raw || !save) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_rays_save: null argument");
   MlpArgs a{};
   a.rays_o = rays_o; a.rays_d = rays_d; a.tvals = tvals; a.t_ray_stride = t_ray_stride;
   a.n_points = n_rays * n_samples; a.n_samples = n_samples; a.packed = (const float*)packed; a.raw = raw; a.save = save;
+  if (precision == NERF_PREC_F32X) {
+    const long long n_tiles = (a.n_points + kXTilePts - 1) / kXTilePts;
+    const unsigned blocks = (unsigned)(n_tiles < num_cus() ? n_tiles : num_cus());
+    hipLaunchKernelGGL((nerf_mlp_f32x_kernel<true, true>), dim3(blocks), dim3(kXThreads), 0, (hipStream_t)stream, a);
+    return check_launch("nerf_mlp_f32x_kernel<save>");
+  }
+  if (precision != NERF_PREC_F32) return fail(NERF_ERR_UNSUPPORTED, "%s", "nerf_mlp_forward_rays_save: f32 or f32x only");
   const long long tiles = (a.n_points + nerf::kTilePts - 1) / nerf::kTilePts;
   hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, true>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("nerf_mlp_f32_kernel<save>");

@@ -29,6 +29,7 @@ class RenderFunction(torch.autograd.Function):
         t_c, u = renderer._get_tables(dev)
         S_c, S_f = _lib.N_SAMPLES, _lib.N_SAMPLES + _lib.N_IMPORTANCE
         pk_c, pk_f = net.packed(""), net.packed("fine")
+        prec = _lib.PRECISIONS[getattr(net, "precision", "f32")]
         f32 = dict(dtype=torch.float32, device=dev)
         raw_c = torch.empty((n, S_c, 4), **f32)
         save_c = torch.empty(int(lib.nerf_train_save_floats(n * S_c)), **f32)
@@ -38,11 +39,11 @@ class RenderFunction(torch.autograd.Function):
         rgb, depth = torch.empty((n, 3), **f32), torch.empty((n,), **f32)
         with torch.cuda.device(dev):
             _lib.check(lib.nerf_mlp_forward_rays_save(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t_c), 0, n, S_c,
-                                                      pk_c.data_ptr(), _lib.ptr(raw_c), _lib.ptr(save_c), st), "forward(coarse)")
+                                                      pk_c.data_ptr(), _lib.ptr(raw_c), _lib.ptr(save_c), prec, st), "forward(coarse)")
             _lib.check(lib.nerf_sample_fine(_lib.ptr(raw_c), _lib.ptr(t_c), _lib.ptr(u), n, _lib.ptr(t_sorted), None, None,
                                             0.0, 0.0, st), "nerf_sample_fine")
             _lib.check(lib.nerf_mlp_forward_rays_save(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t_sorted), S_f, n, S_f,
-                                                      pk_f.data_ptr(), _lib.ptr(raw_f), _lib.ptr(save_f), st), "forward(fine)")
+                                                      pk_f.data_ptr(), _lib.ptr(raw_f), _lib.ptr(save_f), prec, st), "forward(fine)")
             _lib.check(lib.nerf_composite(_lib.ptr(raw_f), _lib.ptr(t_sorted), S_f, n, S_f, int(bool(renderer.white_bkgd)),
                                           _lib.ptr(rgb), _lib.ptr(depth), None, st), "nerf_composite")
         ctx.renderer = renderer
@@ -97,8 +98,9 @@ def render_with_grad(renderer, rays_o, rays_d):
     """rays [n,3] (contiguous fp32, on the GPU) -> (rgb [n,3], depth [n]) attached to the autograd graph of
     the 48 network parameters (coarse sub-model first, then fine, state_dict order)."""
     net = renderer.net
-    if getattr(net, "precision", "f32") != "f32":
-        raise NotImplementedError("training runs on the exact fp32 path")
+    if getattr(net, "precision", "f32") not in ("f32", "f32x"):
+        raise NotImplementedError("training runs on the fp32-accurate paths: precision 'f32' (exact fp32 MFMA) or 'f32x' "
+                                  "(forward on split-fp16 MFMA; the backward kernels are fp32 MFMA either way)")
     if renderer.N_importance != _lib.N_IMPORTANCE or renderer.fast_sampling:
         raise NotImplementedError("training path is built for N_importance=128 without fast_sampling")
     params = tuple(net.model.ordered_params()) + tuple(net.model_fine.ordered_params())

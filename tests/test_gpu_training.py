@@ -24,19 +24,22 @@ def _rel(got, ref):
     return ((got.double().cpu() - ref.double()).abs().max() / ref.double().abs().max().clamp_min(1e-9)).item()
 
 
-def test_forward_save_matches_reference_activations(amd, net, golden):
+@pytest.mark.parametrize("precision", ["f32", "f32x"])
+def test_forward_save_matches_reference_activations(amd, net, golden, precision):
     """SAVE-mode forward: every tensor autograd would keep for NeRF.forward (network.py:49-74) equals
     the reference's own per-layer activations (forward hooks in oracle/gen_golden.py)."""
     g = golden("mlp_layers.npz")
     lib, L = amd._lib.load(), amd._lib
     P = 128
+    net.precision = precision
+    prec = L.PRECISIONS[precision]
     o, d = g["pts"].cuda().contiguous(), g["viewdirs"].cuda().contiguous()     # one-sample rays: x = o + d*0
     t = torch.zeros(P, 1, device="cuda")
     for model, tag in (("", "coarse"), ("fine", "fine")):
         raw = torch.empty(P, 1, 4, device="cuda")
         save = torch.full((int(lib.nerf_train_save_floats(P)),), float("nan"), device="cuda")
         L.check(lib.nerf_mlp_forward_rays_save(L.ptr(o), L.ptr(d), L.ptr(t), 1, P, 1, net.packed(model).data_ptr(),
-                                               L.ptr(raw), L.ptr(save), L.stream_of(o.device)))
+                                               L.ptr(raw), L.ptr(save), prec, L.stream_of(o.device)))
         sv = save.cpu()
         assert torch.isfinite(sv).all()
         pe, dpe = sv[:P * 64].view(P, 64), sv[P * 64:P * 96].view(P, 32)
@@ -50,6 +53,7 @@ def test_forward_save_matches_reference_activations(amd, net, golden):
         hv = sv[P * (96 + 2304):].view(P, 128)
         assert _rel(f, g[f"{tag}_feature"]) <= 2e-5 and _rel(hv, g[f"{tag}_views"]) <= 2e-5
         assert _rel(raw[:, 0], g[f"{tag}_out"]) <= 2e-5
+    net.precision = "f32"
 
 
 @pytest.mark.parametrize("aligned", [False, True])
@@ -115,7 +119,7 @@ def test_mlp_backward_matches_autograd(amd, net, oracle, synthetic_sd, model, pr
     gsave = torch.empty(int(lib.nerf_train_grad_floats(P)), device="cuda")
     g_t = torch.empty(n, S, device="cuda")
     L.check(lib.nerf_mlp_forward_rays_save(L.ptr(od), L.ptr(dd), L.ptr(td), S, n, S, net.packed(model).data_ptr(),
-                                           L.ptr(raw), L.ptr(save), st))
+                                           L.ptr(raw), L.ptr(save), 0, st))
     grads = [torch.zeros_like(p) for p in params]
     L.check(lib.nerf_mlp_backward(L.ptr(od), L.ptr(dd), L.ptr(td), S, n, S, L.ptr(pk_b), L.ptr(Gd), L.ptr(save),
                                   L.ptr(gsave), L.ptr(g_t), _grad_ptrs(amd, grads), st))
@@ -185,13 +189,15 @@ def test_sample_backward_matches_autograd(amd, oracle, golden):
     assert (err <= 1e-3).float().mean() >= 0.98
 
 
-def test_training_step_matches_reference_autograd(amd, synthetic_sd, golden):
+@pytest.mark.parametrize("precision", ["f32", "f32x"])
+def test_training_step_matches_reference_autograd(amd, synthetic_sd, golden, precision):
     """The reference's own training semantics: MSE on the fine RGB of a 64-ray batch,
     loss.backward() -- loss and all 48 gradients from oracle/gen_golden.py's autograd fixture."""
     g = golden("autograd.npz")
     net = amd.Network()
     net.load_state_dict(synthetic_sd, strict=True)
     net = net.cuda().train()
+    net.precision = precision            # "f32x": forward on split-fp16 MFMA, backward kernels fp32 MFMA
     ren = amd.Renderer(net)
     rgb, dep = ren.render({"rays_o": g["rays_o"][None].cuda(), "rays_d": g["rays_d"][None].cuda()})
     assert rgb.requires_grad
