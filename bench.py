@@ -162,7 +162,8 @@ def train_bench(pkg, sd, dev, args, world, rank):
         print(json.dumps({"metric": "rays/sec (training, 4096 rays/iter, 64+128, fwd+bwd+Adam)",
                           "value": round(n_rays * world / (ms * 1e-3), 1), "unit": "rays/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32" if net.precision == "f32" else "f32x (split-fp16 fwd/bwd chains, fp32 weight-gradient MFMA)",
                           "data": "synthetic",
                           "config": {"workload": "BASELINE.json configs[2]: 4096 rays/iter per GPU, MSE on fine RGB, clip 40, "
                                                  "Adam 5e-4; data parallel: one 4.77 MB gradient all-reduce per step"},

@@ -89,18 +89,20 @@ int32_t nerf_mlp_forward_rays_save(const float* rays_o, const float* rays_d, con
                                    const void* packed, float* raw, float* save, int32_t precision, void* stream);
 
 /* Backward of the MLP (network.py:49-74 under autograd) for the points of nerf_mlp_forward_rays_save.
- * `packed_bwd` is the transposed weight stream of nerf_pack_model_bwd (nerf_packed_bwd_floats floats);
+ * `packed_bwd` is the transposed weight stream of nerf_pack_model_bwd (nerf_packed_bwd_bytes(precision) bytes;
+ * precision NERF_PREC_F32: exact fp32 MFMA chain, NERF_PREC_F32X: split-fp16 chain; weight gradients are fp32 MFMA);
  * `draw` [P,4] is d loss / d raw; `save` the forward's activation store; `gsave` scratch of
  * nerf_train_grad_floats(P) floats (receives every layer's pre-activation gradient).  Adds the 24
  * parameter gradients (state_dict order, nn.Linear layouts; the caller zeroes them) and, if `g_t` [P]
  * is given, writes d loss / d t through the points (x = o + d t, positional encoding included) -- the
  * path by which the coarse network is trained. */
 int64_t nerf_train_grad_floats(int64_t n_points);
-int64_t nerf_packed_bwd_floats(void);
-int32_t nerf_pack_model_bwd(const float* const params[24], float* packed_bwd, void* stream);
+int64_t nerf_packed_bwd_bytes(int32_t precision);
+int32_t nerf_pack_model_bwd(const float* const params[24], void* packed_bwd, int32_t precision, void* stream);
 int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float* tvals, int64_t t_ray_stride,
-                          int64_t n_rays, int32_t n_samples, const float* packed_bwd, const float* draw,
-                          const float* save, float* gsave, float* g_t, float* const grads[24], void* stream);
+                          int64_t n_rays, int32_t n_samples, const void* packed_bwd, const float* draw,
+                          const float* save, float* gsave, float* g_t, float* const grads[24], int32_t precision,
+                          void* stream);
 
 /* Adjoint of nerf_composite (autograd of volume_renderer.py:414-432 with :67-96): g_rgb [n,3], g_depth [n]
  * (nullable) -> g_raw [n,S,4] and, if given, g_t [n,S] (the direct dependence of the image on the sample

@@ -12,6 +12,7 @@
 #include "nerf_mlp_f32x.hip.inc"
 #include "nerf_wgrad_f32.hip.inc"
 #include "nerf_mlp_bwd_f32.hip.inc"
+#include "nerf_mlp_bwd_f32x.hip.inc"
 
 namespace {
 
@@ -168,6 +169,49 @@ __device__ __forceinline__ float f16_stream_value(const PackArgs& a, int F, int 
     if (row < 3) v = a.p[P_WR][row * 128 + 16 * s + cj];
   }
   return v;
+}
+
+// backward f32x stream: transposed weights as (hi, lo) fragment pairs + w_alpha / w_rgb in the const region
+__global__ void nerf_pack_bwd_f32x_kernel(PackArgs a) {
+  using namespace nerf;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr long long n_const = kF16ConstBytes / 4;
+  constexpr long long n_el = (long long)kXbSteps * 512;
+  if (i < n_const) {
+    float v = 0.0f;
+    if (i < 256) { const int h = (int)i >> 7, slot = (int)i & 127; v = a.p[P_WA][act_feat(slot >> 4, slot & 15, h)]; }
+    else if (i < 256 + 384) { const int rel = (int)i - 256, c = rel >> 7, h = (rel >> 6) & 1, slot = rel & 63;
+                              v = a.p[P_WR][c * 128 + act_feat(slot >> 4, slot & 15, h)]; }
+    a.out[i] = v;
+    return;
+  }
+  const long long e = i - n_const;
+  if (e >= n_el) return;
+  const int F = (int)(e >> 9), lane = (int)((e >> 3) & 63), j = (int)(e & 7);
+  const int hk = lane >> 5, irow = lane & 31;
+  // locate (layer, m, s): W^T fragment value = W[krow = out feature of the layer][col = in feature]
+  const float* W; int ld, coff = 0, ks, f; bool pe_out = false;
+  if (F < kXbStepsWfT) { f = F - kXbStepsWvT; ks = 8; W = a.p[P_WV]; ld = 283; }
+  else if (F < kXbStepsW5aT) { const int rel = F - kXbStepsWfT, li = rel >> 7; f = rel & 127; ks = 16;
+    if (li == 0) { W = a.p[P_WF]; ld = 256; } else if (li == 1) { W = a.p[14]; ld = 256; }
+    else if (li == 2) { W = a.p[12]; ld = 256; } else { W = a.p[10]; ld = 319; coff = 63; } }
+  else if (F < kXbStepsW4T) { f = F - kXbStepsW5aT; ks = 16; W = a.p[10]; ld = 319; pe_out = true; }
+  else if (F < kXbStepsW0T) { const int rel = F - kXbStepsW4T, li = 4 - (rel >> 7); f = rel & 127; ks = 16; W = a.p[2 * li]; ld = 256; }
+  else { f = F - kXbStepsW0T; ks = 16; W = a.p[P_W0]; ld = 63; pe_out = true; }
+  const int m = f / ks, s = f % ks;
+  const int krow = act16_feat(s, j, hk);
+  float v;
+  if (!pe_out) v = W[(long long)krow * ld + coff + 32 * m + irow];
+  else {
+    const int hp = (irow >> 2) & 1, rp = (irow & 3) + 4 * (irow >> 3);
+    const int c = pe_xyz_feat(16 * m + rp, hp);
+    v = c < 0 ? 0.0f : W[(long long)krow * ld + c];
+  }
+  _Float16* out = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(a.out) + kF16ConstBytes);
+  const _Float16 hi = (_Float16)v;
+  const long long base = ((long long)(2 * F) << 9) + (e & 511);
+  out[base] = hi;
+  out[base + 512] = (_Float16)((v - (float)hi) * 2048.0f);
 }
 
 // fp16 stream (nerf_layout.h "fp16-activation path"): const region (fp32 biases) + A fragments; with SPLIT the
@@ -1022,10 +1066,27 @@ int32_t nerf_adam_step(int32_t n_tensors, float* const params[], const float* co
 }
 
 int64_t nerf_train_grad_floats(int64_t n_points) { return n_points < 0 ? -1 : TrainGrad::floats(n_points); }
-int64_t nerf_packed_bwd_floats(void) { return nerf::kBwdPackedFloats; }
+int64_t nerf_packed_bwd_bytes(int32_t precision) {
+  if (precision == NERF_PREC_F32) return nerf::kBwdPackedFloats * (int64_t)sizeof(float);
+  if (precision == NERF_PREC_F32X) return nerf::kXbPackedBytes;
+  return -1;
+}
 
-int32_t nerf_pack_model_bwd(const float* const params[24], float* packed_bwd, void* stream) {
+int32_t nerf_pack_model_bwd(const float* const params[24], void* packed_bwd_v, int32_t precision, void* stream) {
+  float* packed_bwd = (float*)packed_bwd_v;
   if (!params || !packed_bwd) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_pack_model_bwd: null argument");
+  if (precision == NERF_PREC_F32X) {
+    PackArgs a;
+    for (int i = 0; i < nerf::P_COUNT; ++i) {
+      if (!params[i]) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_pack_model_bwd: null parameter pointer");
+      a.p[i] = params[i];
+    }
+    a.out = packed_bwd;
+    const long long n = nerf::kF16ConstBytes / 4 + (long long)nerf::kXbSteps * 512;
+    hipLaunchKernelGGL(nerf_pack_bwd_f32x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("nerf_pack_bwd_f32x_kernel");
+  }
+  if (precision != NERF_PREC_F32) return fail(NERF_ERR_UNSUPPORTED, "%s", "nerf_pack_model_bwd: f32 or f32x only");
   PackArgs a;
   for (int i = 0; i < nerf::P_COUNT; ++i) {
     if (!params[i]) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_pack_model_bwd: null parameter pointer");
@@ -1038,8 +1099,10 @@ int32_t nerf_pack_model_bwd(const float* const params[24], float* packed_bwd, vo
 
 // grads[24]: device pointers in state_dict order (nn.Linear layouts), accumulated into (caller zeroes them)
 int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float* tvals, int64_t t_ray_stride,
-                          int64_t n_rays, int32_t n_samples, const float* packed_bwd, const float* draw,
-                          const float* save, float* gsave, float* g_t, float* const grads[24], void* stream) {
+                          int64_t n_rays, int32_t n_samples, const void* packed_bwd_v, const float* draw,
+                          const float* save, float* gsave, float* g_t, float* const grads[24], int32_t precision,
+                          void* stream) {
+  const float* packed_bwd = (const float*)packed_bwd_v;
   if (n_rays < 0 || n_samples <= 0 || t_ray_stride < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_backward: bad size");
   if (n_rays == 0) return NERF_OK;
   if (!rays_o || !rays_d || !tvals || !packed_bwd || !draw || !save || !gsave || !grads)
@@ -1049,9 +1112,17 @@ int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float*
   BwdArgs a;
   a.rays_o = rays_o; a.rays_d = rays_d; a.tvals = tvals; a.t_ray_stride = t_ray_stride; a.n_points = P; a.n_samples = n_samples;
   a.packed_bwd = packed_bwd; a.draw = draw; a.save = save; a.gsave = gsave; a.g_t = g_t;
-  const long long tiles = (P + nerf::kTilePts - 1) / nerf::kTilePts;
-  hipLaunchKernelGGL(nerf_mlp_bwd_f32_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
-  int rc = check_launch("nerf_mlp_bwd_f32_kernel");
+  int rc;
+  if (precision == NERF_PREC_F32X) {
+    const long long n_tiles = (P + kXTilePts - 1) / kXTilePts;
+    const unsigned blocks = (unsigned)(n_tiles < num_cus() ? n_tiles : num_cus());
+    hipLaunchKernelGGL(nerf_mlp_bwd_f32x_kernel, dim3(blocks), dim3(kXThreads), 0, (hipStream_t)stream, a);
+    rc = check_launch("nerf_mlp_bwd_f32x_kernel");
+  } else if (precision == NERF_PREC_F32) {
+    const long long tiles = (P + nerf::kTilePts - 1) / nerf::kTilePts;
+    hipLaunchKernelGGL(nerf_mlp_bwd_f32_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    rc = check_launch("nerf_mlp_bwd_f32_kernel");
+  } else return fail(NERF_ERR_UNSUPPORTED, "%s", "nerf_mlp_backward: f32 or f32x only");
   if (rc) return rc;
   // weight / bias gradients: grad_W = g_z^T @ input, grad_b = sum g_z   (network.py:22-47 layers)
   const float* pe = save + TrainSave::off_pe(P);

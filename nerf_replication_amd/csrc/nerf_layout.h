@@ -103,6 +103,16 @@ constexpr int64_t kF16PackedBytes = kF16ConstBytes + (int64_t)kF16Frags * kF16Fr
 constexpr int kXFrags = 2 * kF16Frags;                       // (hi, lo) pairs
 constexpr int kXChunks = kXFrags / kF16ChunkFrags;           // 74
 constexpr int64_t kXPackedBytes = kF16ConstBytes + (int64_t)kXFrags * kF16FragBytes;
+// backward f32x stream (nerf_mlp_bwd_f32x.hip.inc): (hi, lo) pairs of transposed-weight fragments
+constexpr int kXbStepsWvT = 0;                          // 8 m x 8 s
+constexpr int kXbStepsWfT = kXbStepsWvT + 64;           // Wf^T, W7^T, W6^T, W5[:,63:]^T : 8 m x 16 s each
+constexpr int kXbStepsW5aT = kXbStepsWfT + 4 * 128;     // 2 m x 16 s (PE slots)
+constexpr int kXbStepsW4T = kXbStepsW5aT + 32;          // W4^T .. W1^T
+constexpr int kXbStepsW0T = kXbStepsW4T + 4 * 128;      // 2 m x 16 s (PE slots)
+constexpr int kXbSteps = kXbStepsW0T + 32;              // 1152
+constexpr int kXbChunks = 2 * kXbSteps / kF16ChunkFrags;   // 72
+static_assert((2 * kXbSteps) % kF16ChunkFrags == 0, "backward stream must be whole chunks");
+constexpr int64_t kXbPackedBytes = kF16ConstBytes + (int64_t)2 * kXbSteps * kF16FragBytes;
 // offsets (floats) inside the const region
 constexpr int kF16OffBias = 0;                   // 9 x [2][128]
 constexpr int kF16OffBiasViews = 9 * 256;        // [2][64]

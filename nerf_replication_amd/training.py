@@ -47,6 +47,7 @@ class RenderFunction(torch.autograd.Function):
             _lib.check(lib.nerf_composite(_lib.ptr(raw_f), _lib.ptr(t_sorted), S_f, n, S_f, int(bool(renderer.white_bkgd)),
                                           _lib.ptr(rgb), _lib.ptr(depth), None, st), "nerf_composite")
         ctx.renderer = renderer
+        ctx.prec = prec
         ctx.n = n
         ctx.params = params
         ctx.save_for_backward(rays_o, rays_d, raw_c, save_c, t_sorted, raw_f, save_f)
@@ -65,7 +66,8 @@ class RenderFunction(torch.autograd.Function):
         g_rgb = g_rgb.contiguous().to(torch.float32)
         g_depth = None if g_depth is None else g_depth.contiguous().to(torch.float32)
         grads = [torch.zeros_like(p, dtype=torch.float32) for p in params]          # 24 coarse + 24 fine
-        nbwd = int(lib.nerf_packed_bwd_floats())
+        prec = ctx.prec
+        nbwd = int(lib.nerf_packed_bwd_bytes(prec))
         with torch.cuda.device(dev):
             # fine pass: image -> raw_fine and depths; MLP backward; points -> depths
             g_raw_f = torch.empty((n, S_f, 4), **f32)
@@ -74,23 +76,23 @@ class RenderFunction(torch.autograd.Function):
                                                    int(bool(renderer.white_bkgd)), _lib.ptr(g_rgb),
                                                    None if g_depth is None else _lib.ptr(g_depth),
                                                    _lib.ptr(g_raw_f), _lib.ptr(g_t), st), "nerf_composite_backward")
-            pk_b = torch.empty(nbwd, **f32)
-            _lib.check(lib.nerf_pack_model_bwd(_ptr_array([p.detach().contiguous() for p in params[24:]]), _lib.ptr(pk_b), st))
+            pk_b = torch.empty(nbwd, dtype=torch.uint8, device=dev)
+            _lib.check(lib.nerf_pack_model_bwd(_ptr_array([p.detach().contiguous() for p in params[24:]]), pk_b.data_ptr(), prec, st))
             gsave = torch.empty(int(lib.nerf_train_grad_floats(n * S_f)), **f32)
             g_t_pts = torch.empty((n, S_f), **f32)
             _lib.check(lib.nerf_mlp_backward(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t_sorted), S_f, n, S_f,
-                                             _lib.ptr(pk_b), _lib.ptr(g_raw_f), _lib.ptr(save_f), _lib.ptr(gsave),
-                                             _lib.ptr(g_t_pts), _ptr_array(grads[24:]), st), "nerf_mlp_backward(fine)")
+                                             pk_b.data_ptr(), _lib.ptr(g_raw_f), _lib.ptr(save_f), _lib.ptr(gsave),
+                                             _lib.ptr(g_t_pts), _ptr_array(grads[24:]), prec, st), "nerf_mlp_backward(fine)")
             g_t.add_(g_t_pts)                     # plumbing: one elementwise add of two [n,192] buffers
             # coarse pass: depths -> coarse density -> coarse MLP parameters
             g_raw_c = torch.empty((n, S_c, 4), **f32)
             _lib.check(lib.nerf_sample_fine_backward(_lib.ptr(raw_c), _lib.ptr(t_c), _lib.ptr(u), n, _lib.ptr(t_sorted),
                                                      _lib.ptr(g_t), _lib.ptr(g_raw_c), st), "nerf_sample_fine_backward")
-            _lib.check(lib.nerf_pack_model_bwd(_ptr_array([p.detach().contiguous() for p in params[:24]]), _lib.ptr(pk_b), st))
+            _lib.check(lib.nerf_pack_model_bwd(_ptr_array([p.detach().contiguous() for p in params[:24]]), pk_b.data_ptr(), prec, st))
             gsave_c = gsave[: int(lib.nerf_train_grad_floats(n * S_c))]
             _lib.check(lib.nerf_mlp_backward(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t_c), 0, n, S_c,
-                                             _lib.ptr(pk_b), _lib.ptr(g_raw_c), _lib.ptr(save_c), _lib.ptr(gsave_c),
-                                             None, _ptr_array(grads[:24]), st), "nerf_mlp_backward(coarse)")
+                                             pk_b.data_ptr(), _lib.ptr(g_raw_c), _lib.ptr(save_c), _lib.ptr(gsave_c),
+                                             None, _ptr_array(grads[:24]), prec, st), "nerf_mlp_backward(coarse)")
         return (None, None, None) + tuple(g.to(p.dtype) for g, p in zip(grads, params))
 
 

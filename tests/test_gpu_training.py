@@ -86,8 +86,9 @@ def _grad_ptrs(amd, grads):
     return (ctypes.c_void_p * 24)(*[g.data_ptr() for g in grads])
 
 
+@pytest.mark.parametrize("precision", ["f32", "f32x"])
 @pytest.mark.parametrize("model,prefix", [("fine", "model_fine"), ("", "model")])
-def test_mlp_backward_matches_autograd(amd, net, oracle, synthetic_sd, model, prefix):
+def test_mlp_backward_matches_autograd(amd, net, oracle, synthetic_sd, model, prefix, precision):
     """loss = sum(raw * G): all 24 parameter gradients of one NeRF MLP and d loss / d t through the
     points (positional encoding included) against the CPU oracle under torch autograd."""
     import ctypes
@@ -110,8 +111,9 @@ def test_mlp_backward_matches_autograd(amd, net, oracle, synthetic_sd, model, pr
     params = [p.detach().contiguous() for p in sub.ordered_params()]
     arr = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in params])
     st = L.stream_of(params[0].device)
-    pk_b = torch.empty(int(lib.nerf_packed_bwd_floats()), device="cuda")
-    L.check(lib.nerf_pack_model_bwd(arr, L.ptr(pk_b), st))
+    prec = L.PRECISIONS[precision]
+    pk_b = torch.empty(int(lib.nerf_packed_bwd_bytes(prec)), dtype=torch.uint8, device="cuda")
+    L.check(lib.nerf_pack_model_bwd(arr, pk_b.data_ptr(), prec, st))
     P = n * S
     od, dd, td, Gd = o.cuda(), d.cuda(), t.cuda(), G.cuda().contiguous()
     raw = torch.empty(n, S, 4, device="cuda")
@@ -121,8 +123,8 @@ def test_mlp_backward_matches_autograd(amd, net, oracle, synthetic_sd, model, pr
     L.check(lib.nerf_mlp_forward_rays_save(L.ptr(od), L.ptr(dd), L.ptr(td), S, n, S, net.packed(model).data_ptr(),
                                            L.ptr(raw), L.ptr(save), 0, st))
     grads = [torch.zeros_like(p) for p in params]
-    L.check(lib.nerf_mlp_backward(L.ptr(od), L.ptr(dd), L.ptr(td), S, n, S, L.ptr(pk_b), L.ptr(Gd), L.ptr(save),
-                                  L.ptr(gsave), L.ptr(g_t), _grad_ptrs(amd, grads), st))
+    L.check(lib.nerf_mlp_backward(L.ptr(od), L.ptr(dd), L.ptr(td), S, n, S, pk_b.data_ptr(), L.ptr(Gd), L.ptr(save),
+                                  L.ptr(gsave), L.ptr(g_t), _grad_ptrs(amd, grads), prec, st))
     torch.cuda.synchronize()
     assert _rel(raw, raw_ref.detach()) <= 2e-5
     names = [f"{prefix}.{k}" for k in oracle.SUBMODEL_KEYS]
@@ -133,7 +135,7 @@ def test_mlp_backward_matches_autograd(amd, net, oracle, synthetic_sd, model, pr
         worst = max(worst, err)
         assert err <= 2e-4, (name, err)
     e_t = _rel(g_t, t_ref.grad)
-    print(f"{prefix}: worst parameter-gradient error {worst:.2e}, d/dt error {e_t:.2e}")
+    print(f"{prefix} [{precision}]: worst parameter-gradient error {worst:.2e}, d/dt error {e_t:.2e}")
     assert e_t <= 2e-4
 
 
