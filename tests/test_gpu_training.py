@@ -86,9 +86,10 @@ def _grad_ptrs(amd, grads):
     return (ctypes.c_void_p * 24)(*[g.data_ptr() for g in grads])
 
 
+@pytest.mark.parametrize("gscale", [1.0, 1e-7])          # mean-reduced losses hand over gradients around 1e-6 .. 1e-8
 @pytest.mark.parametrize("precision", ["f32", "f32x"])
 @pytest.mark.parametrize("model,prefix", [("fine", "model_fine"), ("", "model")])
-def test_mlp_backward_matches_autograd(amd, net, oracle, synthetic_sd, model, prefix, precision):
+def test_mlp_backward_matches_autograd(amd, net, oracle, synthetic_sd, model, prefix, precision, gscale):
     """loss = sum(raw * G): all 24 parameter gradients of one NeRF MLP and d loss / d t through the
     points (positional encoding included) against the CPU oracle under torch autograd."""
     import ctypes
@@ -99,7 +100,8 @@ def test_mlp_backward_matches_autograd(amd, net, oracle, synthetic_sd, model, pr
     d = torch.randn(n, 3, generator=gen) * 0.2 + torch.tensor([0.0, 0.0, -1.0])
     d = (d / d.norm(dim=-1, keepdim=True)).contiguous()
     t = (torch.sort(torch.rand(n, S, generator=gen) * 4 + 2, dim=-1).values).contiguous()
-    G = torch.randn(n, S, 4, generator=gen)
+    G = torch.randn(n, S, 4, generator=gen) * gscale
+    G[3] = 0.0                                              # a ray that contributes no gradient
     # ---- oracle
     sd = {k: v.clone().requires_grad_(k.startswith(prefix + ".")) for k, v in synthetic_sd.items()}
     t_ref = t.clone().requires_grad_(True)
@@ -135,7 +137,7 @@ def test_mlp_backward_matches_autograd(amd, net, oracle, synthetic_sd, model, pr
         worst = max(worst, err)
         assert err <= 2e-4, (name, err)
     e_t = _rel(g_t, t_ref.grad)
-    print(f"{prefix} [{precision}]: worst parameter-gradient error {worst:.2e}, d/dt error {e_t:.2e}")
+    print(f"{prefix} [{precision}, |G|~{gscale:g}]: worst parameter-gradient error {worst:.2e}, d/dt error {e_t:.2e}")
     assert e_t <= 2e-4
 
 
