@@ -13,6 +13,7 @@
 #include "nerf_wgrad_f32.hip.inc"
 #include "nerf_mlp_bwd_f32.hip.inc"
 #include "nerf_mlp_bwd_f32x.hip.inc"
+#include "nerf_wgrad_bf16x3.hip.inc"
 
 namespace {
 
@@ -1139,16 +1140,35 @@ int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float*
   WG(draw, 4, 3, 1, H(7), 256, 0, 256, grads[P_WA], 256, 0, grads[P_BA]);               // alpha_linear
   WG(gzv, 128, 0, 128, f, 256, 0, 256, grads[P_WV], 283, 0, grads[P_BV]);               // views_linears.0 [feature | dirs]
   WG(gzv, 128, 0, 128, dpe, 32, 0, 27, grads[P_WV], 283, 256, nullptr);
-  WG(gf, 256, 0, 256, H(7), 256, 0, 256, grads[P_WF], 256, 0, grads[P_BF]);             // feature_linear
-  for (int l = 7; l >= 1; --l) {
-    if (l == 5) {                                                                      // skip: [pts63 | h4]
-      WG(GZ(5), 256, 0, 256, pe, 64, 0, 63, grads[10], 319, 0, grads[11]);
-      WG(GZ(5), 256, 0, 256, H(4), 256, 0, 256, grads[10], 319, 63, nullptr);
-    } else {
-      WG(GZ(l), 256, 0, 256, H(l - 1), 256, 0, 256, grads[2 * l], 256, 0, grads[2 * l + 1]);
+  WG(GZ(5), 256, 0, 256, pe, 64, 0, 63, grads[10], 319, 0, grads[11]);                  // skip layer, PE part (+ bias)
+  WG(GZ(0), 256, 0, 256, pe, 64, 0, 63, grads[P_W0], 63, 0, grads[P_B0]);
+  if (precision == NERF_PREC_F32X) {
+    // the eight 256 x 256 blocks in one launch on the bf16x3 path (nerf_wgrad_bf16x3.hip.inc)
+    WgradXArgs w;
+    w.n_points = P; w.n_jobs = 0;
+    auto job = [&](const float* dz, const float* hin, float* dw, int ldw, int wc0, float* db) {
+      WgradXJob& j = w.job[w.n_jobs++];
+      j.dz = dz; j.hin = hin; j.dw = dw; j.db = db; j.ldz = 256; j.zc0 = 0; j.ldh = 256; j.hc0 = 0; j.ldw = ldw; j.wc0 = wc0;
+    };
+    job(gf, H(7), grads[P_WF], 256, 0, grads[P_BF]);
+    for (int l = 7; l >= 1; --l) {
+      if (l == 5) job(GZ(5), H(4), grads[10], 319, 63, nullptr);
+      else job(GZ(l), H(l - 1), grads[2 * l], 256, 0, grads[2 * l + 1]);
+    }
+    const long long steps = (P + 15) / 16;
+    long long slices = num_cus() / w.n_jobs;
+    if (slices > steps) slices = steps;
+    if (slices < 1) slices = 1;
+    hipLaunchKernelGGL(nerf_wgrad256_bf16x3_kernel, dim3((unsigned)(slices * w.n_jobs)), dim3(256), 0, (hipStream_t)stream, w);
+    rc = check_launch("nerf_wgrad256_bf16x3_kernel");
+    if (rc) return rc;
+  } else {
+    WG(gf, 256, 0, 256, H(7), 256, 0, 256, grads[P_WF], 256, 0, grads[P_BF]);           // feature_linear
+    for (int l = 7; l >= 1; --l) {
+      if (l == 5) WG(GZ(5), 256, 0, 256, H(4), 256, 0, 256, grads[10], 319, 63, nullptr);   // skip layer, hidden part
+      else WG(GZ(l), 256, 0, 256, H(l - 1), 256, 0, 256, grads[2 * l], 256, 0, grads[2 * l + 1]);
     }
   }
-  WG(GZ(0), 256, 0, 256, pe, 64, 0, 63, grads[P_W0], 63, 0, grads[P_B0]);
 #undef WG
   return NERF_OK;
 }
