@@ -1148,7 +1148,7 @@ int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float*
     w.n_points = P; w.n_jobs = 0;
     auto job = [&](const float* dz, const float* hin, float* dw, int ldw, int wc0, float* db) {
       WgradXJob& j = w.job[w.n_jobs++];
-      j.dz = dz; j.hin = hin; j.dw = dw; j.db = db; j.ldz = 256; j.zc0 = 0; j.ldh = 256; j.hc0 = 0; j.ldw = ldw; j.wc0 = wc0;
+      j.dz = dz; j.hin = hin; j.dw = dw; j.db = db; j.ldz = 256; j.zc0 = 0; j.ldh = 256; j.hc0 = 0; j.ldw = ldw; j.wc0 = wc0;   // ld 256: the kernel assumes 1-KiB rows
     };
     job(gf, H(7), grads[P_WF], 256, 0, grads[P_BF]);
     for (int l = 7; l >= 1; --l) {
