@@ -1013,6 +1013,19 @@ int32_t nerf_wgrad(const float* dz, int64_t ldz, int32_t zc0, int32_t n_out, con
     a.osplit = 2; a.isplit = 2;
     hipLaunchKernelGGL(nerf_wgrad256_f32_kernel, grid, blk, 0, st, a);
   }
+  // small layers on the vector-load kernel: (floats per lane, wave split) chosen so that 32*AV*osplit covers n_out
+  // and 32*BV*isplit covers n_in; operands must be aligned to their vector width
+  else if (n_out == 256 && n_in <= 64 && aligned) {                                      // PE -> 256 (layers 0 and 5)
+    a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<4, 1>), grid, blk, 0, st, a);
+  } else if (n_out == 128 && n_in == 256 && aligned) {                                   // views_linears.0, feature part
+    a.osplit = 1; a.isplit = 4; hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<4, 2>), grid, blk, 0, st, a);
+  } else if (n_out == 128 && n_in <= 32) {                                               // views_linears.0, direction part
+    a.osplit = 4; a.isplit = 1; hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<1, 1>), grid, blk, 0, st, a);
+  } else if (n_out <= 32 && n_in == 256 && ldh % 2 == 0 && hc0 % 2 == 0 && (uintptr_t)hin % 8 == 0) {   // alpha_linear
+    a.osplit = 1; a.isplit = 4; hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<1, 2>), grid, blk, 0, st, a);
+  } else if (n_out <= 32 && n_in <= 128) {                                               // rgb_linear
+    a.osplit = 1; a.isplit = 4; hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<1, 1>), grid, blk, 0, st, a);
+  }
   else if (to > 4 && ti > 4) { a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<4, 4>), grid, blk, 0, st, a); }
   else if (to > 4)           { a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<4, 1>), grid, blk, 0, st, a); }
   else if (to > 1 && ti > 4) { a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<2, 4>), grid, blk, 0, st, a); }
