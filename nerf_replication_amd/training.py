@@ -65,7 +65,12 @@ class RenderFunction(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         g_rgb = g_rgb.contiguous().to(torch.float32)
         g_depth = None if g_depth is None else g_depth.contiguous().to(torch.float32)
-        grads = [torch.zeros_like(p, dtype=torch.float32) for p in params]          # 24 coarse + 24 fine
+        # 24 coarse + 24 fine gradient tensors as views of one zeroed buffer (one memset instead of 48)
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+        grads, off = [], 0
+        for p in params:
+            grads.append(flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
         prec = ctx.prec
         nbwd = int(lib.nerf_packed_bwd_bytes(prec))
         with torch.cuda.device(dev):
@@ -150,8 +155,14 @@ class FusedAdam:
                                           arr([v for _, _, v in live]), numel, self.lr, self.betas[0], self.betas[1], self.eps,
                                           self.weight_decay, self.clip_value, self.step_count, _lib.stream_of(dev)),
                        "nerf_adam_step")
-        for p, _, _ in live:          # the packed weight streams are keyed on (data_ptr, _version): an in-place no-op
-            p.add_(0)                 # bumps _version so Network.packed() repacks (cache invalidation only)
+        # the packed weight streams are keyed on (data_ptr, _version): tell autograd the HIP kernel wrote in place,
+        # so Network.packed() repacks (cache invalidation only, no kernel launched)
+        bump = getattr(torch.autograd.graph, "increment_version", None)
+        for p, _, _ in live:
+            if bump is not None:
+                bump(p)
+            else:
+                p.add_(0)
 
 
 def train_step(renderer, optimizer, rays_o, rays_d, colors, clip_value=40.0, group=None):
