@@ -120,7 +120,7 @@ def cpu_baseline(sd, n_sample, budget_s=20.0):
         rgb, dep = orc.render(sd, o[None], d[None])
         dt = time.perf_counter() - t0
     return {"value": n_sample / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_sample} random rays of the same 800x800 frame, 64+128, oracle/nerf_oracle.py "
+            "sample": f"{n_sample} random rays of the same {H}x{W} frame, 64+128, oracle/nerf_oracle.py "
                       f"(torch CPU fp32, 512-point MLP chunks), {dt:.1f} s, {cores} threads "
                       f"(os.cpu_count()={os.cpu_count()})"}, (ids, rgb, dep)
 
@@ -181,10 +181,15 @@ def main():
     ap.add_argument("--mode", default="render", choices=["render", "train"],
                     help="render (default: the headline 800x800 frame) or train (BASELINE config 3: 4096 rays/iter, "
                          "fused fwd+bwd HIP MLP + Adam; prints its own JSON line)")
+    ap.add_argument("--res", type=int, default=800,
+                    help="frame is res x res pixels (default 800 = the headline workload; 1600 = BASELINE configs[4], "
+                         "camera_angle_x unchanged)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32x"],
                     help="f32 (default, the reference's dtype: exact fp32 MFMA), f16 (BASELINE config 5: fp16 "
                          "activations, fp32 accumulate) or f32x (fp32-accurate: hi/lo split operands, 3 fp16 MFMAs per product)")
     args = ap.parse_args()
+    global H, W
+    H = W = args.res
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -261,7 +266,7 @@ def main():
     traffic, traffic_src = None, None
     try:      # HBM bytes per launch come from separate rocprofv3 --pmc passes (cannot be read in-process);
         tj = json.load(open(os.path.join(REPO, "profiles", f"traffic_{args.precision}.json")))   # only for the profiled workload
-        if world == 1:
+        if world == 1 and H == 800:
             traffic, traffic_src = tj["traffic_bytes_per_launch"], f"profiles/traffic_{args.precision}.json (rocprofv3 --pmc, not this run)"
     except (OSError, ValueError, KeyError):
         pass
@@ -271,12 +276,12 @@ def main():
                 "stage_ms": {k: round(v, 3) for k, v in stages.items()}}
 
     if rank == 0:
-        out = {"metric": "rays/sec (800x800, 64+128 samples)", "value": round(value, 1), "unit": "rays/s",
+        out = {"metric": f"rays/sec ({H}x{W}, 64+128 samples)", "value": round(value, 1), "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": {0: "f32", 1: "f16 (fp32 accumulate)", 2: "f32 emulated (hi/lo fp16 split x3, fp32 accumulate)"}[prec],
                "data": "synthetic",
-               "config": {"workload": "lego-shaped 800x800 frame = 640000 pinhole rays, 64 coarse + 128 fine "
+               "config": {"workload": f"lego-shaped {H}x{W} frame = {H * W} pinhole rays, 64 coarse + 128 fine "
                                       "hierarchical samples, 8+1-layer W=256 NeRF x2, seeded synthetic weights "
                                       "(latest.pth unavailable offline); BASELINE.json configs[1]",
                           "rays_per_step": n, "parallelism": f"ray-tile shard x{world} + 1 all_gather"},
