@@ -283,7 +283,8 @@ def main():
                "data": "synthetic",
                "config": {"workload": f"lego-shaped {H}x{W} frame = {H * W} pinhole rays, 64 coarse + 128 fine "
                                       "hierarchical samples, 8+1-layer W=256 NeRF x2, seeded synthetic weights "
-                                      "(latest.pth unavailable offline); BASELINE.json configs[1]",
+                                      "(latest.pth unavailable offline); BASELINE.json "
+                                      + ("configs[1]" if H == 800 else "configs[4] frame size" if H == 1600 else "custom frame size"),
                           "rays_per_step": n, "parallelism": f"ray-tile shard x{world} + 1 all_gather"},
                "roofline": roofline}
         if world == 1 and args.cpu_sample > 0:
