@@ -36,6 +36,22 @@ def render_sharded(renderer, rays_o, rays_d, group=None):
     return full[:n, :3].contiguous(), full[:n, 3].contiguous()
 
 
+def _shared_flat_view(grads):
+    """If the gradient tensors are back-to-back contiguous views of ONE storage (in this order), return a 1-D
+    tensor over exactly that range (no copy); otherwise None."""
+    g0 = grads[0]
+    if g0.dtype != torch.float32 or not g0.is_contiguous():
+        return None
+    expect = g0.storage_offset()
+    for g in grads:
+        if (g.dtype != torch.float32 or not g.is_contiguous() or g.storage_offset() != expect
+                or g.untyped_storage().data_ptr() != g0.untyped_storage().data_ptr()):
+            return None
+        expect += g.numel()
+    total = expect - g0.storage_offset()
+    return g0.new_empty(0).set_(g0.untyped_storage(), g0.storage_offset(), (total,))
+
+
 def allreduce_gradients(params, group=None):
     """Data-parallel training (what DDP does for the reference in trainer.py:16-21): average the 48 parameter
     gradients over the ranks with ONE all_reduce of a flat 4.77 MB buffer (2 x 595 844 fp32), then scatter
@@ -44,6 +60,11 @@ def allreduce_gradients(params, group=None):
         return
     params = [p for p in params if p.grad is not None]
     if not params:
+        return
+    flat = _shared_flat_view([p.grad for p in params])
+    if flat is not None:          # training.RenderFunction hands out views of one buffer: reduce it in place
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(dist.get_world_size(group))
         return
     flat = torch.cat([p.grad.reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)

@@ -80,7 +80,7 @@ def test_shard_bounds_cover_every_ray_once():
             assert all(hi - lo <= per for lo, hi, per in spans)
 
 
-def _grad_worker(rank, world, port, out_dir):
+def _grad_worker(rank, world, port, out_dir, shared):
     import sys
     for p in (REPO,):
         sys.path.insert(0, p)
@@ -90,18 +90,34 @@ def _grad_worker(rank, world, port, out_dir):
         from nerf_replication_amd.dist import allreduce_gradients
         torch.manual_seed(0)
         params = [torch.nn.Parameter(torch.zeros(s)) for s in ((256, 63), (256,), (3, 128), (1,))]
-        for i, p in enumerate(params):
-            p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+        if shared:          # the layout training.RenderFunction produces: views of one zeroed buffer, in order
+            flat = torch.zeros(sum(p.numel() for p in params) + 7)
+            off = 3                                                  # a storage offset, and slack at the end
+            for i, p in enumerate(params):
+                p.grad = flat[off:off + p.numel()].view(p.shape)
+                p.grad.fill_(float(rank + 1) * (i + 1))
+                off += p.numel()
+        else:
+            for i, p in enumerate(params):
+                p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
         params.append(torch.nn.Parameter(torch.zeros(5)))            # no gradient: skipped
+        from nerf_replication_amd.dist import _shared_flat_view
+        assert (_shared_flat_view([p.grad for p in params[:-1]]) is not None) == shared
         allreduce_gradients(params)
+        if shared:
+            assert torch.all(flat[:3] == 0) and torch.all(flat[-4:] == 0)      # nothing outside the range touched
         torch.save([p.grad for p in params[:-1]], os.path.join(out_dir, f"g{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
-def test_gradient_allreduce_averages_over_ranks(tmp_path):
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_gradient_allreduce_averages_over_ranks(tmp_path, shared):
     port = _free_port()
-    mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_grad_worker, args=(2, port, str(tmp_path), shared), nprocs=2, join=True)
     for r in range(2):
         grads = torch.load(os.path.join(tmp_path, f"g{r}.pt"))
         for i, g in enumerate(grads):
