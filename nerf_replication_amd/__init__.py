@@ -12,5 +12,6 @@ from .volume_renderer import Renderer       # noqa: F401
 from .rays import generate_rays             # noqa: F401
 from .evaluator import Evaluator            # noqa: F401
 from . import _lib                          # noqa: F401
+from .checkpoint import load_network, load_model, save_model   # noqa: F401
 
-__all__ = ["NeRF", "Network", "Renderer", "Evaluator", "generate_rays"]
+__all__ = ["NeRF", "Network", "Renderer", "Evaluator", "generate_rays", "load_network", "load_model", "save_model"]

@@ -128,6 +128,40 @@ class FusedAdam:
         self.exp_avg = [torch.zeros_like(p, dtype=torch.float32) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p, dtype=torch.float32) for p in self.params]
 
+    # torch.optim.Adam's state_dict layout, so checkpoints (checkpoint.save_model / the reference's save_model,
+    # net_utils.py:323-343) move freely between this optimizer and torch.optim.Adam
+    def state_dict(self):
+        state = {}
+        if self.step_count > 0:
+            for i, (m, v) in enumerate(zip(self.exp_avg, self.exp_avg_sq)):
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m, "exp_avg_sq": v}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "clip_value": self.clip_value, "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
+            raise ValueError("FusedAdam.load_state_dict: expected one parameter group of {} tensors".format(len(self.params)))
+        g = groups[0]
+        if g.get("amsgrad", False) or g.get("maximize", False):
+            raise ValueError("FusedAdam does not implement amsgrad / maximize")
+        self.lr, self.betas, self.eps = g["lr"], tuple(g["betas"]), g["eps"]
+        self.weight_decay = g.get("weight_decay", 0.0)
+        self.clip_value = g.get("clip_value", self.clip_value)
+        steps = set()
+        for i, p in enumerate(self.params):
+            st = sd["state"].get(i, sd["state"].get(str(i)))
+            if st is None:
+                self.exp_avg[i].zero_(); self.exp_avg_sq[i].zero_()
+                continue
+            self.exp_avg[i].copy_(st["exp_avg"]); self.exp_avg_sq[i].copy_(st["exp_avg_sq"])
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("FusedAdam.load_state_dict: tensors are at different steps {}".format(sorted(steps)))
+        self.step_count = steps.pop() if steps else 0
+
     def zero_grad(self, set_to_none=True):
         for p in self.params:
             if set_to_none:

@@ -1,0 +1,68 @@
+"""Checkpoint compatibility with the reference's file layout (src/utils/net_utils.py:288-379): CPU-only."""
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def amd_cpu():
+    """The package itself imports without a GPU (only the kernels need one)."""
+    import nerf_replication_amd
+    return nerf_replication_amd
+
+
+def test_load_network_reads_reference_layout(amd_cpu, tmp_path, synthetic_sd):
+    net = amd_cpu.Network()
+    # a file path, as run.py passes cfg.trained_model_dir when it is a file
+    assert amd_cpu.load_network(net, os.path.join(GOLDEN, "synthetic_ckpt.pth")) == 1        # fixture has epoch 0
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, synthetic_sd[k])
+    assert amd_cpu.load_network(net, str(tmp_path / "missing")) == 0
+    assert amd_cpu.load_network(net, os.path.join(GOLDEN, "synthetic_ckpt.pth"), resume=False) == 0
+
+
+def test_save_model_rotation_and_resume(amd_cpu, tmp_path, synthetic_sd):
+    from nerf_replication_amd.training import FusedAdam
+    net = amd_cpu.Network()
+    net.load_state_dict(synthetic_sd)
+    opt = FusedAdam(net.parameters(), lr=3e-4)
+    opt.step_count = 7
+    opt.exp_avg[0].fill_(0.25); opt.exp_avg_sq[3].fill_(2.0)
+    d = str(tmp_path / "ckpt")
+    for ep in range(7):
+        amd_cpu.save_model(net, opt, None, None, d, ep)
+    assert sorted(os.listdir(d)) == ["2.pth", "3.pth", "4.pth", "5.pth", "6.pth"]             # five numbered files kept
+    amd_cpu.save_model(net, opt, None, None, d, 9, last=True)
+    assert "latest.pth" in os.listdir(d)
+
+    net2 = amd_cpu.Network()
+    opt2 = FusedAdam(net2.parameters())
+    assert amd_cpu.load_model(net2, opt2, None, None, d) == 10                                # latest.pth wins: epoch 9 + 1
+    assert opt2.step_count == 7 and opt2.lr == 3e-4
+    assert torch.all(opt2.exp_avg[0] == 0.25) and torch.all(opt2.exp_avg_sq[3] == 2.0)
+    assert amd_cpu.load_model(net2, opt2, None, None, d, epoch=4) == 5
+    assert amd_cpu.load_network(net2, d, epoch=-1) == 10
+
+
+def test_fused_adam_state_dict_interoperates_with_torch_adam(amd_cpu, synthetic_sd):
+    from nerf_replication_amd.training import FusedAdam
+    net = amd_cpu.Network()
+    net.load_state_dict(synthetic_sd)
+    ref = torch.optim.Adam(net.parameters(), lr=5e-4, eps=1e-8)
+    for p in net.parameters():
+        p.grad = torch.full_like(p, 1e-3)
+    ref.step(); ref.step()
+    fused = FusedAdam(net.parameters())
+    fused.load_state_dict(ref.state_dict())                       # torch -> fused
+    assert fused.step_count == 2
+    for i, p in enumerate(net.parameters()):
+        assert torch.equal(fused.exp_avg[i], ref.state[p]["exp_avg"])
+    ref2 = torch.optim.Adam(net.parameters(), lr=1.0)
+    ref2.load_state_dict(fused.state_dict())                      # fused -> torch
+    assert ref2.param_groups[0]["lr"] == 5e-4
+    for p in net.parameters():
+        assert torch.equal(ref2.state[p]["exp_avg_sq"], ref.state[p]["exp_avg_sq"])
+        assert float(ref2.state[p]["step"]) == 2.0
