@@ -228,7 +228,8 @@ def test_training_step_matches_reference_autograd(amd, synthetic_sd, golden, pre
         assert torch.all(dict(net.named_parameters())[k].grad == 0), k
 
 
-def test_short_training_run_reduces_loss(amd, oracle, synthetic_sd):
+@pytest.mark.parametrize("precision", ["f32", "f32x"])
+def test_short_training_run_reduces_loss(amd, oracle, synthetic_sd, precision):
     """Config-3-shaped loop (render -> MSE on fine RGB -> backward -> clip 40 -> Adam): the fine colour
     head is knocked off a target image and trained back; the loss must fall, which also exercises the
     re-packing of the weight streams after every optimizer step."""
@@ -237,6 +238,7 @@ def test_short_training_run_reduces_loss(amd, oracle, synthetic_sd):
     net = amd.Network()
     net.load_state_dict(synthetic_sd, strict=True)
     net = net.cuda().train()
+    net.precision = precision
     ren = amd.Renderer(net)
     ids = torch.randperm(800 * 800, generator=torch.Generator().manual_seed(9))[:1024]
     o, d = oracle.pinhole_rays(800, 800, oracle.camera_pose(20.0), pixel_ids=ids)
@@ -251,7 +253,7 @@ def test_short_training_run_reduces_loss(amd, oracle, synthetic_sd):
     opt = torch.optim.Adam(head, lr=2e-2, eps=1e-8)
     before = [p.detach().clone() for p in net.model_fine.pts_linears[3].parameters()]
     losses = [train_step(ren, opt, o, d, target).item() for _ in range(25)]
-    print("losses", ["%.5f" % l for l in losses[::4]])
+    print(f"losses [{precision}]", ["%.5f" % l for l in losses[::4]])
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < 0.25 * losses[0]
     for b, p in zip(before, net.model_fine.pts_linears[3].parameters()):
         assert torch.equal(b, p.detach()) and p.grad is not None          # not in the optimizer: untouched, but has a gradient
