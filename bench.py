@@ -163,7 +163,7 @@ def train_bench(pkg, sd, dev, args, world, rank):
                           "value": round(n_rays * world / (ms * 1e-3), 1), "unit": "rays/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "f32" if net.precision == "f32" else "f32x (split-fp16 fwd/bwd chains, fp32 weight-gradient MFMA)",
+                          "dtype": "f32" if net.precision == "f32" else "f32x (split-fp16 fwd/bwd chains, bf16x3 weight gradients for the 256x256 layers, fp32 MFMA for the small ones)",
                           "data": "synthetic",
                           "config": {"workload": "BASELINE.json configs[2]: 4096 rays/iter per GPU, MSE on fine RGB, clip 40, "
                                                  "Adam 5e-4; data parallel: one 4.77 MB gradient all-reduce per step"},
