@@ -30,17 +30,18 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
             continue
         key = (r["Kernel_Name"].split("(")[0][-40:], r["Grid_Size"], r["Counter_Name"])
         out.setdefault(key, []).append(float(r["Counter_Value"]))
-with open(os.path.join(here, f"{tag}_pmc.csv"), "w", newline="") as f:
-    w = csv.writer(f)
-    w.writerow(["kernel", "grid_size", "counter", "dispatches", "mean_value", "note"])
-    for (k, g, c), v in sorted(out.items()):
-        m = sum(v) / len(v)
-        note = ""
-        if c == "FETCH_SIZE":
-            note = f"KiB units; x2 gfx950 wide-read correction -> {m * 1024 * 2 / 1e6:.1f} MB/dispatch"
-        elif c == "WRITE_SIZE":
-            note = f"KiB units -> {m * 1024 / 1e6:.1f} MB/dispatch"
-        w.writerow([k, g, c, len(v), f"{m:.0f}", note])
+if out:          # (trace-only collections have no counter passes: no empty file)
+  with open(os.path.join(here, f"{tag}_pmc.csv"), "w", newline="") as f:
+      w = csv.writer(f)
+      w.writerow(["kernel", "grid_size", "counter", "dispatches", "mean_value", "note"])
+      for (k, g, c), v in sorted(out.items()):
+          m = sum(v) / len(v)
+          note = ""
+          if c == "FETCH_SIZE":
+              note = f"KiB units; x2 gfx950 wide-read correction -> {m * 1024 * 2 / 1e6:.1f} MB/dispatch"
+          elif c == "WRITE_SIZE":
+              note = f"KiB units -> {m * 1024 / 1e6:.1f} MB/dispatch"
+          w.writerow([k, g, c, len(v), f"{m:.0f}", note])
 
 # traffic_<prec>.json: what bench.py reports as roofline.traffic (per launch of the dominant kernel, averaged over the
 # coarse and fine launches exactly as `rocprofv3 --stats` averages their durations)
