@@ -188,6 +188,10 @@ def main():
     ap.add_argument("--res", type=int, default=800,
                     help="frame is res x res pixels (default 800 = the headline workload; 1600 = BASELINE configs[4], "
                          "camera_angle_x unchanged)")
+    ap.add_argument("--fast-sampling", action="store_true",
+                    help="the reference's optional ESS/ERT masked fine pass (volume_renderer.py:132-244, off in lego.yaml): "
+                         "fine samples the coarse pass marks empty or occluded skip the MLP; a different image, reported "
+                         "as its own metric")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32x"],
                     help="f32 (default, the reference's dtype: exact fp32 MFMA), f16 (BASELINE config 5: fp16 "
                          "activations, fp32 accumulate) or f32x (fp32-accurate: hi/lo split operands, 3 fp16 MFMAs per product)")
@@ -230,6 +234,7 @@ def main():
     # f32x executes 3 fp16 MFMAs per algorithmic MAC: its ceiling in ALGORITHMIC flops is a third of the fp16 peak
     peak = {0: PEAK_F32_MFMA, 1: PEAK_F16_MFMA, 2: PEAK_F16_MFMA / 3.0}[prec]
     ren = pkg.Renderer(net)
+    ren.fast_sampling = bool(args.fast_sampling)
     # the frame's rays are generated on the device by nerf_generate_rays (dataset formula,
     # blender.py:102-127), resident in HBM before the timed region starts
     o, d = pkg.generate_rays(camera_pose_40(), H, W, 0.6911112070083618, dev)
@@ -280,7 +285,7 @@ def main():
                 "stage_ms": {k: round(v, 3) for k, v in stages.items()}}
 
     if rank == 0:
-        out = {"metric": f"rays/sec ({H}x{W}, 64+128 samples)", "value": round(value, 1), "unit": "rays/s",
+        out = {"metric": f"rays/sec ({H}x{W}, 64+128 samples)" + (", ESS/ERT masked fine pass" if args.fast_sampling else ""), "value": round(value, 1), "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": {0: "f32", 1: "f16 (fp32 accumulate)", 2: "f32 emulated (hi/lo fp16 split x3, fp32 accumulate)"}[prec],
@@ -289,7 +294,9 @@ def main():
                                       "hierarchical samples, 8+1-layer W=256 NeRF x2, seeded synthetic weights "
                                       "(latest.pth unavailable offline); BASELINE.json "
                                       + ("configs[1]" if H == 800 else "configs[4] frame size" if H == 1600 else "custom frame size"),
-                          "rays_per_step": n, "parallelism": f"ray-tile shard x{world} + 1 all_gather"},
+                          "rays_per_step": n, "parallelism": f"ray-tile shard x{world} + 1 all_gather",
+                          **({"fast_sampling": "ESS/ERT masks, weights_threshold %.2f; the roofline block times the UNMASKED "
+                                               "MLP launches" % ren.weights_threshold} if args.fast_sampling else {})},
                "roofline": roofline}
         if world == 1 and args.cpu_sample > 0:
             base, (ids, ref_rgb, ref_dep) = cpu_baseline(sd, args.cpu_sample)
