@@ -114,89 +114,111 @@ def render_with_grad(renderer, rays_o, rays_d):
     return RenderFunction.apply(renderer, rays_o, rays_d, *params)
 
 
-class FusedAdam:
-    """clip_grad_value_ + Adam in one HIP launch over all parameter tensors (nerf_adam_step).  Same update
-    as torch.optim.Adam(lr, eps, weight_decay) of src/train/optimizer.py:21-24; `lr` may be changed between
-    steps (ExponentialLR of src/utils/optimizer/lr_scheduler.py:68-79: lr0 * gamma ** (epoch / decay_epochs))."""
+class FusedAdam(torch.optim.Optimizer):
+    """clip_grad_value_ + Adam in one HIP launch over all parameter tensors of a group (nerf_adam_step).  Same update
+    as torch.optim.Adam(lr, eps, weight_decay) of src/train/optimizer.py:21-24 preceded by trainer.py:59's
+    clip_grad_value_(40).  It IS a torch.optim.Optimizer (param_groups, state, state_dict in torch.optim.Adam's layout),
+    so the reference's schedulers (ExponentialLR / MultiStepLR of src/utils/optimizer/lr_scheduler.py, built by
+    make_lr_scheduler) and its save_model / load_model (net_utils.py:288-343) drive it unchanged, and a checkpoint
+    moves freely between this optimizer and torch.optim.Adam."""
 
     def __init__(self, params, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_value=40.0):
-        self.params = [p for p in params if p.requires_grad]
-        if len(self.params) > 48:
-            raise ValueError("FusedAdam handles at most 48 tensors per launch")
-        self.lr, self.betas, self.eps, self.weight_decay, self.clip_value = lr, betas, eps, weight_decay, clip_value
-        self.step_count = 0
-        self.exp_avg = [torch.zeros_like(p, dtype=torch.float32) for p in self.params]
-        self.exp_avg_sq = [torch.zeros_like(p, dtype=torch.float32) for p in self.params]
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, clip_value=clip_value,
+                        amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None)
+        super().__init__([p for p in params if not isinstance(p, torch.Tensor) or p.requires_grad], defaults)
+        for g in self.param_groups:
+            if len(g["params"]) > 48:
+                raise ValueError("FusedAdam handles at most 48 tensors per parameter group (one launch per group)")
 
-    # torch.optim.Adam's state_dict layout, so checkpoints (checkpoint.save_model / the reference's save_model,
-    # net_utils.py:323-343) move freely between this optimizer and torch.optim.Adam
-    def state_dict(self):
-        state = {}
-        if self.step_count > 0:
-            for i, (m, v) in enumerate(zip(self.exp_avg, self.exp_avg_sq)):
-                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m, "exp_avg_sq": v}
-        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
-                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
-                 "fused": None, "clip_value": self.clip_value, "params": list(range(len(self.params)))}
-        return {"state": state, "param_groups": [group]}
+    def _state_of(self, p):
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = torch.tensor(0.0)
+            st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32)
+            st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32)
+        return st
 
-    def load_state_dict(self, sd):
-        groups = sd["param_groups"]
-        if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
-            raise ValueError("FusedAdam.load_state_dict: expected one parameter group of {} tensors".format(len(self.params)))
-        g = groups[0]
-        if g.get("amsgrad", False) or g.get("maximize", False):
-            raise ValueError("FusedAdam does not implement amsgrad / maximize")
-        self.lr, self.betas, self.eps = g["lr"], tuple(g["betas"]), g["eps"]
-        self.weight_decay = g.get("weight_decay", 0.0)
-        self.clip_value = g.get("clip_value", self.clip_value)
-        steps = set()
-        for i, p in enumerate(self.params):
-            st = sd["state"].get(i, sd["state"].get(str(i)))
-            if st is None:
-                self.exp_avg[i].zero_(); self.exp_avg_sq[i].zero_()
-                continue
-            self.exp_avg[i].copy_(st["exp_avg"]); self.exp_avg_sq[i].copy_(st["exp_avg_sq"])
-            steps.add(int(float(st["step"])))
-        if len(steps) > 1:
-            raise ValueError("FusedAdam.load_state_dict: tensors are at different steps {}".format(sorted(steps)))
-        self.step_count = steps.pop() if steps else 0
+    # conveniences over param_groups[0] / state (tests, bench)
+    @property
+    def params(self):
+        return [p for g in self.param_groups for p in g["params"]]
 
-    def zero_grad(self, set_to_none=True):
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    @lr.setter
+    def lr(self, value):
+        for g in self.param_groups:
+            g["lr"] = value
+
+    @property
+    def clip_value(self):
+        return self.param_groups[0]["clip_value"]
+
+    @property
+    def exp_avg(self):
+        return [self._state_of(p)["exp_avg"] for p in self.params]
+
+    @property
+    def exp_avg_sq(self):
+        return [self._state_of(p)["exp_avg_sq"] for p in self.params]
+
+    @property
+    def step_count(self):
+        return max([int(float(self._state_of(p)["step"])) for p in self.params] or [0])
+
+    @step_count.setter
+    def step_count(self, value):
         for p in self.params:
-            if set_to_none:
-                p.grad = None
-            elif p.grad is not None:
-                p.grad.zero_()
+            self._state_of(p)["step"] = torch.tensor(float(value))
 
     @staticmethod
     def exponential_lr(lr0, epoch, gamma=0.1, decay_epochs=500):
         return lr0 * gamma ** (epoch / decay_epochs)
 
     @torch.no_grad()
-    def step(self):
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         lib = _lib.load()
-        live = [(p, m, v) for p, m, v in zip(self.params, self.exp_avg, self.exp_avg_sq) if p.grad is not None]
-        if not live:
-            return
-        self.step_count += 1
-        dev = live[0][0].device
-        grads = [p.grad.contiguous() for p, _, _ in live]
         arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-        numel = (ctypes.c_int64 * len(live))(*[p.numel() for p, _, _ in live])
-        with torch.cuda.device(dev):
-            _lib.check(lib.nerf_adam_step(len(live), arr([p for p, _, _ in live]), arr(grads), arr([m for _, m, _ in live]),
-                                          arr([v for _, _, v in live]), numel, self.lr, self.betas[0], self.betas[1], self.eps,
-                                          self.weight_decay, self.clip_value, self.step_count, _lib.stream_of(dev)),
-                       "nerf_adam_step")
-        # the packed weight streams are keyed on (data_ptr, _version): tell autograd the HIP kernel wrote in place,
-        # so Network.packed() repacks (cache invalidation only, no kernel launched)
         bump = getattr(torch.autograd.graph, "increment_version", None)
-        for p, _, _ in live:
-            if bump is not None:
-                bump(p)
-            else:
-                p.add_(0)
+        for g in self.param_groups:
+            if g.get("amsgrad", False) or g.get("maximize", False):
+                raise ValueError("FusedAdam does not implement amsgrad / maximize")
+            live = [p for p in g["params"] if p.grad is not None]
+            if not live:
+                continue
+            states = [self._state_of(p) for p in live]
+            steps = {int(float(st["step"])) for st in states}
+            if len(steps) != 1:
+                raise ValueError("FusedAdam: tensors of one group are at different steps {}".format(sorted(steps)))
+            step = steps.pop() + 1
+            dev = live[0].device
+            for st in states:                     # state loaded from a CPU checkpoint follows its parameter
+                for k in ("exp_avg", "exp_avg_sq"):
+                    if st[k].device != dev:
+                        st[k] = st[k].to(dev)
+            grads = [p.grad.contiguous() for p in live]
+            numel = (ctypes.c_int64 * len(live))(*[p.numel() for p in live])
+            with torch.cuda.device(dev):
+                _lib.check(lib.nerf_adam_step(len(live), arr(live), arr(grads), arr([st["exp_avg"] for st in states]),
+                                              arr([st["exp_avg_sq"] for st in states]), numel, float(g["lr"]),
+                                              float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                              float(g["weight_decay"]), float(g.get("clip_value", 40.0)), step,
+                                              _lib.stream_of(dev)), "nerf_adam_step")
+            for p, st in zip(live, states):
+                st["step"] = torch.tensor(float(step))
+                # the packed weight streams are keyed on (data_ptr, _version): tell autograd the HIP kernel wrote in
+                # place, so Network.packed() repacks (cache invalidation only, no kernel launched)
+                if bump is not None:
+                    bump(p)
+                else:
+                    p.add_(0)
+        return loss
 
 
 def train_step(renderer, optimizer, rays_o, rays_d, colors, clip_value=40.0, group=None):

@@ -66,3 +66,32 @@ def test_fused_adam_state_dict_interoperates_with_torch_adam(amd_cpu, synthetic_
     for p in net.parameters():
         assert torch.equal(ref2.state[p]["exp_avg_sq"], ref.state[p]["exp_avg_sq"])
         assert float(ref2.state[p]["step"]) == 2.0
+
+
+def test_fused_adam_is_driven_by_reference_style_schedulers(amd_cpu, synthetic_sd):
+    """The reference builds ExponentialLR / MultiStepLR as torch _LRScheduler subclasses over its optimizer
+    (src/utils/optimizer/lr_scheduler.py:52-79, src/train/scheduler.py): that requires a real torch Optimizer
+    with param_groups.  Same formula restated here: lr = base_lr * gamma ** (epoch / decay_epochs)."""
+    import warnings
+    from nerf_replication_amd.training import FusedAdam
+
+    class ExponentialLR(torch.optim.lr_scheduler._LRScheduler):
+        def __init__(self, optimizer, decay_epochs, gamma=0.1, last_epoch=-1):
+            self.decay_epochs, self.gamma = decay_epochs, gamma
+            super().__init__(optimizer, last_epoch)
+
+        def get_lr(self):
+            return [base_lr * self.gamma ** (self.last_epoch / self.decay_epochs) for base_lr in self.base_lrs]
+
+    net = amd_cpu.Network()
+    opt = FusedAdam(net.parameters(), lr=5e-4)
+    assert isinstance(opt, torch.optim.Optimizer) and len(opt.param_groups) == 1 and len(opt.params) == 48
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                 # "scheduler.step() before optimizer.step()": no GPU here
+        sched = ExponentialLR(opt, decay_epochs=500, gamma=0.1)
+        for _ in range(250):
+            sched.step()
+    assert abs(opt.lr - 5e-4 * 0.1 ** 0.5) < 1e-12
+    assert abs(FusedAdam.exponential_lr(5e-4, 250) - opt.lr) < 1e-15
+    sd = sched.state_dict()
+    assert sd["last_epoch"] == 250
