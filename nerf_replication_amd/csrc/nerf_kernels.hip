@@ -1138,7 +1138,7 @@ int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float*
     rc = check_launch("nerf_mlp_bwd_f32x_kernel");
   } else if (precision == NERF_PREC_F32) {
     const long long tiles = (P + nerf::kTilePts - 1) / nerf::kTilePts;
-    hipLaunchKernelGGL(nerf_mlp_bwd_f32_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(nerf_mlp_bwd_f32_kernel, dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, a);       // barrier-free: one-wave workgroups
     rc = check_launch("nerf_mlp_bwd_f32_kernel");
   } else return fail(NERF_ERR_UNSUPPORTED, "%s", "nerf_mlp_backward: f32 or f32x only");
   if (rc) return rc;
@@ -1209,7 +1209,7 @@ int32_t nerf_mlp_forward_rays_save(const float* rays_o, const float* rays_d, con
   }
   if (precision != NERF_PREC_F32) return fail(NERF_ERR_UNSUPPORTED, "%s", "nerf_mlp_forward_rays_save: f32 or f32x only");
   const long long tiles = (a.n_points + nerf::kTilePts - 1) / nerf::kTilePts;
-  hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, true>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, true>), dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, a);   // barrier-free: one-wave workgroups
   return check_launch("nerf_mlp_f32_kernel<save>");
 }
 
