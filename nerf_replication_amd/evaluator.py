@@ -2,8 +2,13 @@
 `evaluate(output, batch)` accumulates the float MSE of the clipped images (:96-100) and the PSNR of
 `psnr_metric` (:23-30) -- both the value that function really prints (its uint8 subtraction and
 squaring wrap modulo 256) and the float PSNR it was meant to compute -- and, when the batch
-is a whole H x W image, the SSIM of ssim_metric (:49-77, skimage win 7).  The PNG dump is not built."""
+is a whole H x W image, the SSIM of ssim_metric (:49-77, skimage win 7).  With a `result_dir` the predicted and
+ground-truth images are also written as `images/view{id:03d}_pred.png` / `_gt.png` like ssim_metric does (:50-61;
+`(img * 255).astype(uint8)`, RGB), by a small zlib PNG writer (cv2 / imageio are not available here)."""
 import math
+import os
+import struct
+import zlib
 
 import torch
 
@@ -38,9 +43,26 @@ def image_ssim(pred_hw3, gt_hw3):
     return out.item() / ((H - 6) * (W - 6) * 3)
 
 
+def write_png(path, img_hw3_u8):
+    """8-bit RGB PNG (filter 0 on every row); `img_hw3_u8`: uint8 tensor or array [H,W,3]."""
+    img = torch.as_tensor(img_hw3_u8).detach().cpu().to(torch.uint8).contiguous()
+    H, W, C = img.shape
+    if C != 3:
+        raise ValueError("write_png expects [H,W,3]")
+    rows = torch.cat([torch.zeros(H, 1, dtype=torch.uint8), img.reshape(H, W * 3)], dim=1)      # filter byte 0 per row
+    raw = rows.numpy().tobytes()
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, 2, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
 class Evaluator:
-    def __init__(self):
+    def __init__(self, result_dir=None):
         self.mse, self.psnr, self.psnr_float, self.ssim, self.imgs = [], [], [], [], []
+        self.result_dir = result_dir           # cfg.result_dir of the reference: images go to <result_dir>/images
 
     def evaluate(self, output, batch):
         rgb_pred = output[0]
@@ -55,6 +77,13 @@ class Evaluator:
             H, W = int(batch["H"]), int(batch["W"])
             if H * W * 3 == n:
                 self.ssim.append(image_ssim(rgb_pred.reshape(H, W, 3), rgb_gt.reshape(H, W, 3)))
+                if self.result_dir is not None:
+                    d = os.path.join(self.result_dir, "images")
+                    os.makedirs(d, exist_ok=True)
+                    view = int(batch["id"]) if "id" in batch else len(self.ssim) - 1
+                    to_u8 = lambda x: (x.detach().to(torch.float32).clamp(0, 1) * 255).to(torch.uint8).reshape(H, W, 3)
+                    write_png(os.path.join(d, "view{:03d}_pred.png".format(view)), to_u8(rgb_pred))
+                    write_png(os.path.join(d, "view{:03d}_gt.png".format(view)), to_u8(rgb_gt))
 
     def summarize(self):
         mean = lambda v: float(sum(v) / len(v)) if v else 0.0

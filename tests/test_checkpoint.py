@@ -95,3 +95,26 @@ def test_fused_adam_is_driven_by_reference_style_schedulers(amd_cpu, synthetic_s
     assert abs(FusedAdam.exponential_lr(5e-4, 250) - opt.lr) < 1e-15
     sd = sched.state_dict()
     assert sd["last_epoch"] == 250
+
+
+def test_png_writer_round_trip(amd_cpu, tmp_path):
+    """evaluator.write_png (the evaluator's image dump, evaluators/nerf.py:50-61): decode the file again."""
+    import struct, zlib
+    from nerf_replication_amd.evaluator import write_png
+    img = (torch.rand(5, 7, 3, generator=torch.Generator().manual_seed(1)) * 255).to(torch.uint8)
+    path = str(tmp_path / "x.png")
+    write_png(path, img)
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, {}
+    while pos < len(data):
+        n, tag = struct.unpack(">I", data[pos:pos + 4])[0], data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + body) & 0xffffffff
+        chunks[tag] = body
+        pos += 12 + n
+    W, H, depth, ctype = struct.unpack(">IIBB", chunks[b"IHDR"][:10])
+    assert (W, H, depth, ctype) == (7, 5, 8, 2)
+    raw = zlib.decompress(chunks[b"IDAT"])
+    rows = torch.frombuffer(bytearray(raw), dtype=torch.uint8).reshape(5, 1 + 7 * 3)
+    assert torch.all(rows[:, 0] == 0) and torch.equal(rows[:, 1:].reshape(5, 7, 3), img)

@@ -356,7 +356,7 @@ def test_generate_rays_matches_dataset_formula(amd, oracle, golden):
     assert lib.nerf_generate_rays(bad, 800, 800, 1000.0, 639999, 2, None, None, None, None) == -1   # runs off the image
 
 
-def test_evaluator_metrics(amd, oracle):
+def test_evaluator_metrics(amd, oracle, tmp_path):
     gen = torch.Generator().manual_seed(5)
     gt = torch.rand(4000, 3, generator=gen)
     pred = (gt + 0.05 * torch.randn(4000, 3, generator=gen))          # some values leave [0,1] -> clip path
@@ -375,9 +375,11 @@ def test_evaluator_metrics(amd, oracle):
     img = torch.rand(H, W, 3, generator=gen)
     smooth = torch.nn.functional.avg_pool2d(img.permute(2, 0, 1)[None], 5, 1, 2)[0].permute(1, 2, 0)
     noisy = (smooth + 0.03 * torch.randn(H, W, 3, generator=gen)).clamp(0, 1)
-    ev2 = amd.Evaluator()
+    ev2 = amd.Evaluator(result_dir=str(tmp_path))          # also dumps images/view007_{pred,gt}.png (:50-61)
     ev2.evaluate((noisy.reshape(-1, 3).cuda(), None), {"colors": smooth.reshape(1, -1, 3).cuda(),
-                                                      "H": torch.tensor(H), "W": torch.tensor(W)})
+                                                      "H": torch.tensor(H), "W": torch.tensor(W), "id": torch.tensor(7)})
+    import os
+    assert sorted(os.listdir(tmp_path / "images")) == ["view007_gt.png", "view007_pred.png"]
     ref = oracle.evaluator_ssim(noisy, smooth)
     assert 0.3 < ref < 0.999 and abs(ev2.ssim[0] - ref) <= 1e-9
     assert abs(amd.evaluator.image_ssim(smooth.cuda(), smooth.cuda()) - 1.0) <= 1e-12
