@@ -62,3 +62,17 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".inc", ".cpp")):
                 src = open(os.path.join(root, f)).read()
                 assert "nerf_oracle" not in src and "oracle/" not in src, f
+
+
+def test_inline_asm_weight_stream_has_no_register_hazard():
+    """The fp32 inference kernel fills its weight ring with inline-asm loads that complete behind the compiler's
+    back; tools/check_asm_stream.py compiles the kernel to ISA and proves that no instruction touches a ring
+    register between its load and the s_waitcnt that covers it (a spill, copy or reuse there would move stale data)."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_asm_stream.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "784 asm loads, 0 hazards" in r.stdout or " 0 hazards" in r.stdout
