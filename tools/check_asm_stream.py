@@ -34,39 +34,58 @@ def check(lines, name):
     a = next(i for i, l in enumerate(lines) if l.startswith(name + ":"))
     b = next(i for i, l in enumerate(lines) if i > a and ".amdhsa_kernel " + name in l)
     K = lines[a:b]
-    ins = [(i, l.strip()) for i, l in enumerate(K) if l.strip() and not l.strip().startswith((";", "."))]
+    ins, label_at = [], {}
+    for i, l in enumerate(K):
+        t = l.strip()
+        if re.match(r"^\.LBB\d+_\d+:", t):
+            label_at[t.split(":")[0]] = len(ins)                 # index of the first instruction after the label
+        elif t and not t.startswith((";", ".")):
+            ins.append((i, t))
     in_asm = lambda idx: "ASMSTART" in K[ins[idx][0] - 1]
     is_vmem = lambda l: l.startswith(("global_", "buffer_", "scratch_", "flat_"))
     asm_load = lambda idx: ins[idx][1].startswith("global_load_dwordx4") and "s[" in ins[idx][1] and in_asm(idx)
-    # every s_waitcnt with a vmcnt field covers, whoever wrote it (the compiler's own waits count all outstanding
-    # memory operations, the asm loads included)
-    waits = [(idx, int(re.search(r"vmcnt\((\d+)\)", l).group(1))) for idx, (i, l) in enumerate(ins)
-             if l.startswith("s_waitcnt") and "vmcnt(" in l]
-    vm = [idx for idx, (i, l) in enumerate(ins) if is_vmem(l)]
-    loads = [v for v in vm if asm_load(v)]
+    loads = [idx for idx in range(len(ins)) if asm_load(idx)]
     hazards = []
-    for ld in loads:
-        dst = vregs(ins[ld][1].split(",")[0])
-        cover = None
-        for w, cnt in waits:        # the first asm wait with at least `cnt` younger memory operations in between
-            if w > ld and bisect.bisect_left(vm, w) - bisect.bisect_right(vm, ld) >= cnt:
-                cover = w
-                break
-        if cover is None:
-            hazards.append(("never waited for", ins[ld][1], ""))
-            continue
-        for j in range(ld + 1, cover):
-            l = ins[j][1]
-            touched = vregs(l.split(",")[0]) if asm_load(j) else vregs(l)
+
+    def walk(idx, dst, younger, depth, seen):
+        """Follow the control flow from instruction idx until a wait covers the load (at most `cnt` younger memory
+        operations outstanding); report every instruction on the way that touches dst."""
+        steps = 0
+        while idx < len(ins) and steps < 4000:
+            steps += 1
+            if (idx, younger) in seen:
+                return
+            seen.add((idx, younger))
+            l = ins[idx][1]
+            m = re.search(r"vmcnt\((\d+)\)", l) if l.startswith("s_waitcnt") else None
+            if m and younger >= int(m.group(1)):
+                return                                            # covered on this path
+            touched = vregs(l.split(",")[0]) if asm_load(idx) else vregs(l)
             if touched & dst:
-                hazards.append(("touched before its wait", ins[ld][1], l))
+                hazards.append(("touched before its wait", ld_text, l))
+                return
+            if is_vmem(l):
+                younger += 1
+            if l.startswith("s_endpgm"):
+                return
+            if l.startswith("s_branch"):
+                idx = label_at[l.split()[1]]
+                continue
+            if l.startswith("s_cbranch") and depth < 12:
+                walk(label_at[l.split()[1]], dst, younger, depth + 1, seen)
+            idx += 1
+
+    for ld in loads:
+        ld_text = ins[ld][1]
+        walk(ld + 1, vregs(ld_text.split(",")[0]), 0, 0, set())
     return len(loads), hazards
 
 
 def main():
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
-        subprocess.run(f"/opt/rocm/bin/hipcc {FLAGS} -o {out} {SRC}", shell=True, check=True, stderr=subprocess.DEVNULL)
+        extra = os.environ.get("NERF_CHECK_EXTRA_FLAGS", "")     # e.g. -DNERF_F32_ASM_OVERRUN=1: must report hazards
+        subprocess.run(f"/opt/rocm/bin/hipcc {FLAGS} {extra} -o {out} {SRC}", shell=True, check=True, stderr=subprocess.DEVNULL)
         lines = open(out).read().split("\n")
     bad = 0
     for k in KERNELS:
