@@ -1013,7 +1013,11 @@ int32_t nerf_wgrad(const float* dz, int64_t ldz, int32_t zc0, int32_t n_out, con
   hipStream_t st = (hipStream_t)stream;
   const bool aligned = ldz % 4 == 0 && ldh % 4 == 0 && zc0 % 4 == 0 && hc0 % 4 == 0 &&
                        (uintptr_t)dz % 16 == 0 && (uintptr_t)hin % 16 == 0;
-  if (n_out == 256 && n_in == 256 && aligned) {
+  if (n_out == 256 && n_in == 256 && aligned && NERF_WGRAD_ASM && n_points % 16 == 0 && n_points / 16 >= blocks &&
+      ldz * 8 < (1ll << 31) && ldh * 8 < (1ll << 31)) {
+    a.osplit = 2; a.isplit = 2;        // whole groups of 8 k-steps per workgroup: the clamp-free asm-load form
+    hipLaunchKernelGGL(nerf_wgrad256_f32_asm_kernel, grid, blk, 0, st, a);
+  } else if (n_out == 256 && n_in == 256 && aligned) {
     a.osplit = 2; a.isplit = 2;
     hipLaunchKernelGGL(nerf_wgrad256_f32_kernel, grid, blk, 0, st, a);
   }

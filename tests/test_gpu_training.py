@@ -58,7 +58,8 @@ def test_forward_save_matches_reference_activations(amd, net, golden, precision)
 
 @pytest.mark.parametrize("aligned", [False, True])
 @pytest.mark.parametrize("n_out,n_in,P", [(256, 256, 4099), (256, 63, 777), (128, 256, 1000), (128, 27, 333),
-                                           (3, 128, 2050), (1, 256, 513), (256, 256, 1), (256, 256, 200001)])
+                                           (3, 128, 2050), (1, 256, 513), (256, 256, 1), (256, 256, 200001),
+                                           (256, 256, 4096), (256, 256, 200000), (256, 256, 48)])   # multiples of 16: asm-load kernel
 def test_wgrad_gemm(amd, n_out, n_in, P, aligned):
     """grad_weight = grad_out^T @ input and grad_bias = grad_out.sum(0), written into a column block of an
     nn.Linear-shaped [out, in_total] gradient (the skip / view concatenations are column blocks)."""

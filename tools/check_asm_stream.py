@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Static check of the inline-asm weight stream of nerf_mlp_f32_kernel<*, false> (the inference instances).
+"""Static check of the kernels that fill a register ring with inline-asm loads: nerf_mlp_f32_kernel<*, false> (the
+inference instances) and nerf_wgrad256_f32_asm_kernel.
 
 The asm `global_load_dwordx4` loads are asynchronous behind the compiler's back: between a load and the asm
 `s_waitcnt vmcnt(N)` that covers it, NO instruction may read or write the destination registers (the compiler could
@@ -18,7 +19,8 @@ import tempfile
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "nerf_replication_amd", "csrc", "nerf_kernels.hip")
 FLAGS = "-O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -S --cuda-device-only"
-KERNELS = ["_Z19nerf_mlp_f32_kernelILb1ELb0EEv7MlpArgs", "_Z19nerf_mlp_f32_kernelILb0ELb0EEv7MlpArgs"]
+KERNELS = ["_Z19nerf_mlp_f32_kernelILb1ELb0EEv7MlpArgs", "_Z19nerf_mlp_f32_kernelILb0ELb0EEv7MlpArgs",
+           "_Z28nerf_wgrad256_f32_asm_kernel9WgradArgs"]
 
 
 def vregs(text):
