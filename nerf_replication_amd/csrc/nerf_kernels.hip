@@ -1016,7 +1016,9 @@ int32_t nerf_wgrad(const float* dz, int64_t ldz, int32_t zc0, int32_t n_out, con
   if (n_out == 256 && n_in == 256 && aligned && NERF_WGRAD_ASM && n_points % 16 == 0 && n_points / 16 >= blocks &&
       ldz * 8 < (1ll << 31) && ldh * 8 < (1ll << 31)) {
     a.osplit = 2; a.isplit = 2;        // whole groups of 8 k-steps per workgroup: the clamp-free asm-load form
-    hipLaunchKernelGGL(nerf_wgrad256_f32_asm_kernel, grid, blk, 0, st, a);
+    WgradBatch wb;
+    wb.job[0] = a; wb.n_jobs = 1;
+    hipLaunchKernelGGL(nerf_wgrad256_f32_asm_kernel, grid, blk, 0, st, wb);
   } else if (n_out == 256 && n_in == 256 && aligned) {
     a.osplit = 2; a.isplit = 2;
     hipLaunchKernelGGL(nerf_wgrad256_f32_kernel, grid, blk, 0, st, a);
@@ -1182,6 +1184,24 @@ int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float*
     if (slices < 1) slices = 1;
     hipLaunchKernelGGL(nerf_wgrad256_bf16x3_kernel, dim3((unsigned)(slices * w.n_jobs)), dim3(256), 0, (hipStream_t)stream, w);
     rc = check_launch("nerf_wgrad256_bf16x3_kernel");
+    if (rc) return rc;
+  } else if (NERF_WGRAD_ASM && P % 16 == 0 && P / 16 >= num_cus() / 8) {
+    // fp32 MFMA, the eight 256 x 256 blocks in one launch of the asm-load kernel
+    WgradBatch wb;
+    wb.n_jobs = 0;
+    auto job = [&](const float* dz, const float* hin, float* dw, int ldw, int wc0, float* db) {
+      WgradArgs& j = wb.job[wb.n_jobs++];
+      j.dz = dz; j.ldz = 256; j.zc0 = 0; j.n_out = 256; j.hin = hin; j.ldh = 256; j.hc0 = 0; j.n_in = 256;
+      j.dw = dw; j.ldw = ldw; j.wc0 = wc0; j.db = db; j.n_points = P; j.osplit = 2; j.isplit = 2;
+    };
+    job(gf, H(7), grads[P_WF], 256, 0, grads[P_BF]);
+    for (int l = 7; l >= 1; --l) {
+      if (l == 5) job(GZ(5), H(4), grads[10], 319, 63, nullptr);
+      else job(GZ(l), H(l - 1), grads[2 * l], 256, 0, grads[2 * l + 1]);
+    }
+    const long long slices = num_cus() / wb.n_jobs;
+    hipLaunchKernelGGL(nerf_wgrad256_f32_asm_kernel, dim3((unsigned)(slices * wb.n_jobs)), dim3(256), 0, (hipStream_t)stream, wb);
+    rc = check_launch("nerf_wgrad256_f32_asm_kernel");
     if (rc) return rc;
   } else {
     WG(gf, 256, 0, 256, H(7), 256, 0, 256, grads[P_WF], 256, 0, grads[P_BF]);           // feature_linear
