@@ -20,6 +20,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "nerf_replication_amd", "csrc", "nerf_kernels.hip")
 FLAGS = "-O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -S --cuda-device-only"
 KERNELS = ["_Z19nerf_mlp_f32_kernelILb1ELb0EEv7MlpArgs", "_Z19nerf_mlp_f32_kernelILb0ELb0EEv7MlpArgs",
+           "_Z19nerf_mlp_f32_kernelILb1ELb1EEv7MlpArgs",
            "_Z28nerf_wgrad256_f32_asm_kernel10WgradBatch"]
 
 
