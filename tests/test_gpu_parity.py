@@ -541,3 +541,29 @@ def test_config4_second_scene_and_pose(amd, oracle):
     rgb = torch.cat([p[0] for p in parts]); dep = torch.cat([p[1] for p in parts])
     assert torch.equal(rgb, whole[0]) and torch.equal(dep, whole[1])       # tiles == whole frame, bit for bit
     assert_image_close(oracle, rgb, dep, ref_rgb, ref_dep)
+
+
+def test_integration_md_ctypes_stub_runs_verbatim(amd, net):
+    """INTEGRATION.md section 3 shows the ctypes binding a maintainer would write against include/nerf_mi355x.h.
+    The code block is executed as printed and must reproduce the package's Renderer bit for bit."""
+    import os
+    from conftest import REPO
+    src = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    start = src.index("```python\nimport ctypes, torch") + len("```python\n")
+    code = src[start:src.index("```\n", start)].replace('"nerf_replication_amd/libnerf_mi355x.so"',
+                                                        repr(os.path.join(REPO, "nerf_replication_amd", "libnerf_mi355x.so")))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+
+    class Holder:
+        pass
+    r = Holder()
+    r.pk_coarse, r.pk_fine = ns["pack"](net.model), ns["pack"](net.model_fine)
+    gen = torch.Generator().manual_seed(3)
+    o = torch.tensor([0.0, 0.0, 4.0]).expand(300, 3).contiguous().cuda()
+    d = torch.nn.functional.normalize(torch.randn(300, 3, generator=gen) * 0.2 + torch.tensor([0.0, 0.0, -1.0]), dim=-1).cuda()
+    rgb, dep = ns["render"](r, {"rays_o": o[None], "rays_d": d[None]})
+    net.precision = "f32"
+    with torch.no_grad():
+        rgb2, dep2 = amd.Renderer(net).render({"rays_o": o[None], "rays_d": d[None]})
+    assert torch.equal(rgb, rgb2) and torch.equal(dep, dep2)
