@@ -11,11 +11,22 @@ import sys
 import torch
 import torch.nn as nn
 
-if __package__ in (None, ""):                      # loaded by path (imp.load_source): make the package importable
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from nerf_replication_amd import _lib
-else:
-    from . import _lib
+
+def _sibling(name):
+    """Import a sibling module of this package by its absolute name.  The reference loads this file by PATH
+    (imp.load_source(cfg.*_module, cfg.*_path), make_network.py:4-8 / make_renderer.py:4-8), under whatever dotted name
+    the YAML gives and with the CWD -- not necessarily sys.path -- holding the package directory."""
+    import importlib
+    try:
+        return importlib.import_module("nerf_replication_amd." + name)
+    except ModuleNotFoundError as exc:
+        if exc.name != "nerf_replication_amd":
+            raise
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        return importlib.import_module("nerf_replication_amd." + name)
+
+
+_lib = _sibling("_lib")
 
 
 def _reference_cfg():

@@ -11,11 +11,22 @@ import sys
 
 import torch
 
-if __package__ in (None, ""):
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from nerf_replication_amd import _lib
-else:
-    from . import _lib
+
+def _sibling(name):
+    """Import a sibling module of this package by its absolute name.  The reference loads this file by PATH
+    (imp.load_source(cfg.*_module, cfg.*_path), make_network.py:4-8 / make_renderer.py:4-8), under whatever dotted name
+    the YAML gives and with the CWD -- not necessarily sys.path -- holding the package directory."""
+    import importlib
+    try:
+        return importlib.import_module("nerf_replication_amd." + name)
+    except ModuleNotFoundError as exc:
+        if exc.name != "nerf_replication_amd":
+            raise
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        return importlib.import_module("nerf_replication_amd." + name)
+
+
+_lib = _sibling("_lib")
 
 
 def _reference_cfg():
@@ -78,10 +89,7 @@ class Renderer:
                 any(p.requires_grad for p in self.net.parameters()):
             # training call (trainers/nerf.py:27 under trainer.py:53-60): forward with activation save,
             # backward through the adjoint HIP kernels (training.py)
-            if __package__ in (None, ""):
-                from nerf_replication_amd.training import render_with_grad
-            else:
-                from .training import render_with_grad
+            render_with_grad = _sibling("training").render_with_grad
             if n == 0:
                 return torch.empty((0, 3), device=dev), torch.empty((0,), device=dev)
             return render_with_grad(self, o, d)
