@@ -13,7 +13,12 @@ Extra objects on that line:
   roofline      dominant kernel (nerf_mlp_f32_kernel: both launches of a frame), algorithmic FLOP
                 (1 186 816 per MLP point) / HIP-event time, vs 157.3 TFLOP/s fp32 MFMA
   cpu_baseline  the CPU oracle (port of the reference, its 512-point chunking) timed on this host
-                on a bounded sample of the same workload (rank 0, N=1 only)
+                on a bounded sample of the same workload (rank 0, N=1 only); cpu_baseline_config1 is
+                BASELINE.json configs[0] (1024 rays, 64 coarse samples only) on the same host
+  training      BASELINE.json configs[2]: 4096 rays/iter per GPU, fused fwd+bwd HIP MLP + clip + Adam, f32 and f32x
+  config5       BASELINE.json configs[4]: one 1600x1600 frame, fp16 activations / fp32 accumulate, sharded like the headline
+  world_size / per_rank_compute_ms   what torch.distributed really saw, and each rank's own render time per step
+The headline value/metric/dtype are those of configs[1] only; the extra blocks run AFTER its timed region.
 """
 import argparse
 import json
@@ -125,28 +130,28 @@ def cpu_baseline(sd, n_sample, budget_s=20.0):
                       f"(os.cpu_count()={os.cpu_count()})"}, (ids, rgb, dep)
 
 
-def train_bench(pkg, sd, dev, args, world, rank):
-    """BASELINE config 3: 4096 rays per iteration (4 x 1024 random pixels), forward with activation save,
-    backward through the adjoint kernels, clip 40, Adam lr 5e-4 -- the reference's intended step
-    (SURVEY F9).  One "step" = one iteration; value = rays/s of training."""
+def run_training(pkg, sd, dev, precision, steps, warmup, world, rank):
+    """BASELINE config 3: 4096 rays per iteration per GPU (4 x 1024 random pixels), forward with activation save,
+    backward through the adjoint kernels, [one gradient all-reduce], clip 40, Adam lr 5e-4 -- the reference's
+    intended step.  One "step" = one iteration.  Returns the measured block (max over ranks)."""
     from nerf_replication_amd.training import train_step, FusedAdam
     n_rays = 4096
     net = pkg.Network()
     net.load_state_dict(sd, strict=True)
     net = net.to(dev).train()
-    net.precision = args.precision if args.precision in ("f32", "f32x") else "f32"
+    net.precision = precision
     ren = pkg.Renderer(net)
     ids = torch.randperm(H * W, generator=torch.Generator().manual_seed(rank))[:n_rays].to(dev)
     o, d = pkg.generate_rays(camera_pose_40(), H, W, 0.6911112070083618, dev, pixel_ids=ids)
     colors = torch.rand(n_rays, 3, generator=torch.Generator().manual_seed(1)).to(dev)
     opt = FusedAdam(net.parameters(), lr=5e-4, eps=1e-8, clip_value=40.0)      # one launch: clip 40 + Adam
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         train_step(ren, opt, o, d, colors)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = train_step(ren, opt, o, d, colors)
     if world > 1:
         dist.barrier()
@@ -156,24 +161,100 @@ def train_bench(pkg, sd, dev, args, world, rank):
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
-    ms = elapsed / args.steps * 1e3
-    flop = n_rays * POINTS_PER_RAY * FLOP_PER_POINT * 3.0          # fwd + data-grad + weight-grad
+    ms = elapsed / steps * 1e3
+    flop = n_rays * POINTS_PER_RAY * FLOP_PER_POINT * 3.0          # fwd + data-grad + weight-grad, per GPU
+    # f32x: three fp16 (or six bf16) MFMAs per algorithmic MAC -> ceiling = a third of the fp16 peak
+    peak = PEAK_F32_MFMA if precision == "f32" else PEAK_F16_MFMA / 3.0
+    traffic = None
+    try:      # HBM bytes per step from separate rocprofv3 --pmc passes of `bench.py --mode train` (profiles/collect.sh)
+        traffic = json.load(open(os.path.join(REPO, "profiles", f"traffic_train_{precision}.json")))["traffic_bytes_per_step"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return {"rays_per_s": round(n_rays * world / (ms * 1e-3), 1), "ms_per_step": round(ms, 3), "steps": steps,
+            "warmup": warmup, "rays_per_iter_per_gpu": n_rays,
+            "roofline": {"bound": "mfma", "achieved": round(flop / (ms * 1e-3) / 1e12, 2), "peak": round(peak / 1e12, 1),
+                         "unit": "TFLOP/s", "frac": round(flop / (ms * 1e-3) / peak, 4), "traffic": traffic},
+            "final_loss": round(loss.item(), 6)}
+
+
+TRAIN_DTYPE = {"f32": "f32", "f32x": "f32x (split-fp16 fwd/bwd chains, bf16x3 weight gradients for the 256x256 layers, "
+                                     "fp32 MFMA for the small ones)"}
+
+
+def train_bench(pkg, sd, dev, args, world, rank):
+    """`--mode train`: the config-3 step as its own JSON line (what profiles/collect.sh profiles)."""
+    precision = args.precision if args.precision in ("f32", "f32x") else "f32"
+    r = run_training(pkg, sd, dev, precision, args.steps, args.warmup, world, rank)
     if rank == 0:
         print(json.dumps({"metric": "rays/sec (training, 4096 rays/iter, 64+128, fwd+bwd+Adam)",
-                          "value": round(n_rays * world / (ms * 1e-3), 1), "unit": "rays/s", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+                          "value": r["rays_per_s"], "unit": "rays/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "f32" if net.precision == "f32" else "f32x (split-fp16 fwd/bwd chains, bf16x3 weight gradients for the 256x256 layers, fp32 MFMA for the small ones)",
-                          "data": "synthetic",
+                          "dtype": TRAIN_DTYPE[precision], "data": "synthetic",
                           "config": {"workload": "BASELINE.json configs[2]: 4096 rays/iter per GPU, MSE on fine RGB, clip 40, "
                                                  "Adam 5e-4; data parallel: one 4.77 MB gradient all-reduce per step"},
-                          # f32x: three fp16 (or six bf16) MFMAs per algorithmic MAC -> ceiling = a third of the fp16 peak
-                          "roofline": {"bound": "mfma", "achieved": round(flop / (ms * 1e-3) / 1e12, 2),
-                                       "peak": round((PEAK_F32_MFMA if net.precision == "f32" else PEAK_F16_MFMA / 3.0) / 1e12, 1),
-                                       "unit": "TFLOP/s",
-                                       "frac": round(flop / (ms * 1e-3) / (PEAK_F32_MFMA if net.precision == "f32" else PEAK_F16_MFMA / 3.0), 4),
-                                       "traffic": None},
-                          "final_loss": round(loss.item(), 6)}), flush=True)
+                          "roofline": r["roofline"], "final_loss": r["final_loss"]}), flush=True)
+
+
+def run_config5(pkg, sd, dev, world, rank, steps=2):
+    """BASELINE config 5: one 1600x1600 frame (2 560 000 rays, 64+128), fp16 activations / fp32 accumulate, rays
+    sharded over the ranks exactly like the headline frame.  Rays generated per rank for its own tile."""
+    from nerf_replication_amd.dist import render_shard, shard_bounds
+    res = 1600
+    net = pkg.Network()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    net.precision = "f16"
+    ren = pkg.Renderer(net)
+    n = res * res
+    lo, hi, _ = shard_bounds(n, rank, world)
+    o, d = pkg.generate_rays(camera_pose_40(), res, res, 0.6911112070083618, dev, pixel_begin=lo, n_pixels=hi - lo)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        render_shard(ren, o, d, n)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rgb, dep = render_shard(ren, o, d, n)
+        fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    finite = bool(torch.isfinite(rgb).all().item() and torch.isfinite(dep).all().item())
+    rays_per_s = n * steps / elapsed
+    return {"workload": "1600x1600 frame = 2560000 rays, 64+128, fp16 activations + fp32 accumulate (nerf_mlp_f16_kernel)",
+            "rays_per_s": round(rays_per_s, 1), "ms_per_frame": round(elapsed / steps * 1e3, 2), "steps": steps, "warmup": 1,
+            "n_gpus": world, "finite": finite,
+            "roofline": {"bound": "mfma", "achieved": round(rays_per_s * POINTS_PER_RAY * FLOP_PER_POINT / 1e12, 1),
+                         "peak": PEAK_F16_MFMA * world / 1e12, "unit": "TFLOP/s",
+                         "frac": round(rays_per_s * POINTS_PER_RAY * FLOP_PER_POINT / (PEAK_F16_MFMA * world), 4)}}
+
+
+def cpu_baseline_config1(sd):
+    """BASELINE.json configs[0]: 1024-ray batch, 64 coarse samples only (N_importance = 0), the reference's CPU path
+    -- here the oracle port with its 512-point MLP chunks, best of 3, on this host's cores."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import nerf_oracle as orc
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    ids = torch.from_numpy(__import__("numpy").random.default_rng(0).choice(800 * 800, 1024, replace=False))
+    o, d = orc.pinhole_rays(800, 800, orc.camera_pose(40.0), pixel_ids=ids)
+    best = float("inf")
+    with torch.no_grad():
+        for _ in range(4):
+            t0 = time.perf_counter()
+            rgb, dep = orc.render(sd, o[None], d[None], n_importance=0)
+            best = min(best, time.perf_counter() - t0)
+    return {"value": round(1024 / best, 1), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"BASELINE configs[0]: 1024 rays, 64 coarse samples only, best of 4 ({best * 1e3:.0f} ms), "
+                      f"{cores} threads (os.cpu_count()={os.cpu_count()})"}, (o, d, rgb, dep)
 
 
 def main():
@@ -192,6 +273,8 @@ def main():
                     help="the reference's optional ESS/ERT masked fine pass (volume_renderer.py:132-244, off in lego.yaml): "
                          "fine samples the coarse pass marks empty or occluded skip the MLP; a different image, reported "
                          "as its own metric")
+    ap.add_argument("--no-extras", dest="extras", action="store_false",
+                    help="skip the training (configs[2]) and 1600x1600 f16 (configs[4]) blocks that follow the headline")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32x"],
                     help="f32 (default, the reference's dtype: exact fp32 MFMA), f16 (BASELINE config 5: fp16 "
                          "activations, fp32 accumulate) or f32x (fp32-accurate: hi/lo split operands, 3 fp16 MFMAs per product)")
@@ -221,11 +304,14 @@ def main():
             dist.init_process_group(backend)
 
     import nerf_replication_amd as pkg
-    from nerf_replication_amd.dist import render_sharded, shard_bounds
+    from nerf_replication_amd.dist import render_shard, shard_bounds
     pkg._lib.load()                                   # fail loudly without the HIP extension
     sd = load_weights()
     if args.mode == "train":
-        return train_bench(pkg, sd, dev, args, world, rank)
+        train_bench(pkg, sd, dev, args, world, rank)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     net = pkg.Network()
     net.load_state_dict(sd, strict=True)
     net = net.to(dev).eval()
@@ -235,14 +321,16 @@ def main():
     peak = {0: PEAK_F32_MFMA, 1: PEAK_F16_MFMA, 2: PEAK_F16_MFMA / 3.0}[prec]
     ren = pkg.Renderer(net)
     ren.fast_sampling = bool(args.fast_sampling)
-    # the frame's rays are generated on the device by nerf_generate_rays (dataset formula,
-    # blender.py:102-127), resident in HBM before the timed region starts
-    o, d = pkg.generate_rays(camera_pose_40(), H, W, 0.6911112070083618, dev)
-    n = o.shape[0]
+    # every rank generates ONLY its own tile of the frame's rays, on the device (nerf_generate_rays = the dataset
+    # formula, blender.py:102-127), resident in HBM before the timed region starts; no rank holds the whole frame's rays
+    n = H * W
+    lo, hi, _ = shard_bounds(n, rank, world)
+    o, d = pkg.generate_rays(camera_pose_40(), H, W, 0.6911112070083618, dev, pixel_begin=lo, n_pixels=hi - lo)
+    events = []
 
     def step():
         with torch.no_grad():
-            return render_sharded(ren, o, d)
+            return render_shard(ren, o, d, n, events=events)
 
     def fence():
         if world > 1:
@@ -252,23 +340,30 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    del events[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         rgb, dep = step()
     fence()
     elapsed = time.perf_counter() - t0
+    assert rgb.shape == (n, 3) and dep.shape == (n,)
+    my_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))     # this rank's own render time per step
+    per_rank_ms = [my_ms]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+        mine = torch.tensor([my_ms], device=dev, dtype=torch.float64)
+        allms = torch.empty(world, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(allms, mine)
+        per_rank_ms = allms.tolist()
     ms_per_step = elapsed / args.steps * 1e3
     value = n * args.steps / elapsed
     if rank == 0:
         print(f"[bench] {args.steps} steps: {ms_per_step:.1f} ms/step, {value:.0f} rays/s", file=sys.stderr, flush=True)
 
     # dominant-kernel roofline on this rank's shard (HIP events on the launch stream)
-    lo, hi, _ = shard_bounds(n, rank, world)
-    stages = time_stages(pkg, net, ren, o[lo:hi].contiguous(), d[lo:hi].contiguous(), max(1, min(args.steps, 3)), prec)
+    stages = time_stages(pkg, net, ren, o, d, max(1, min(args.steps, 3)), prec)
     mlp_ms_per_launch = (stages["mlp_coarse"] + stages["mlp_fine"]) / 2.0
     flop_per_launch = (hi - lo) * POINTS_PER_RAY * FLOP_PER_POINT / 2.0
     achieved = flop_per_launch / (mlp_ms_per_launch * 1e-3) / 1e12
@@ -284,6 +379,7 @@ def main():
                 "kernel": f"nerf_mlp_{args.precision}_kernel", "avg_launch_ms": round(mlp_ms_per_launch, 3),
                 "stage_ms": {k: round(v, 3) for k, v in stages.items()}}
 
+    out = None
     if rank == 0:
         out = {"metric": f"rays/sec ({H}x{W}, 64+128 samples)" + (", ESS/ERT masked fine pass" if args.fast_sampling else ""), "value": round(value, 1), "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -294,10 +390,15 @@ def main():
                                       "hierarchical samples, 8+1-layer W=256 NeRF x2, seeded synthetic weights "
                                       "(latest.pth unavailable offline); BASELINE.json "
                                       + ("configs[1]" if H == 800 else "configs[4] frame size" if H == 1600 else "custom frame size"),
-                          "rays_per_step": n, "parallelism": f"ray-tile shard x{world} + 1 all_gather",
+                          "rays_per_step": n, "parallelism": f"ray-tile shard x{world} (each rank generates and renders only "
+                                                             "its tile) + 1 all_gather",
                           **({"fast_sampling": "ESS/ERT masks, weights_threshold %.2f; the roofline block times the UNMASKED "
                                                "MLP launches" % ren.weights_threshold} if args.fast_sampling else {})},
-               "roofline": roofline}
+               "roofline": roofline,
+               # self-check for a scaling record: what torch.distributed really ran, and every rank's own render time
+               "world_size": dist.get_world_size() if world > 1 else 1,
+               "dist_backend": (dist.get_backend() if world > 1 else None),
+               "per_rank_compute_ms": [round(x, 3) for x in per_rank_ms]}
         if world == 1 and args.cpu_sample > 0:
             base, (ids, ref_rgb, ref_dep) = cpu_baseline(sd, args.cpu_sample)
             base["value"] = round(base["value"], 1)
@@ -310,6 +411,21 @@ def main():
                 g_rgb, g_dep = ren.render({"rays_o": oo[None].to(dev), "rays_d": dd[None].to(dev)})
             out["psnr_vs_cpu_oracle_db"] = round(orc.psnr(g_rgb.cpu(), ref_rgb), 1)
             out["speedup_vs_cpu_baseline"] = round(value / base["value"], 1)
+            # BASELINE configs[0]: the reference's own CPU-runnable case, and the HIP path on the same 1024 rays
+            c1, (o1, d1, c1_rgb, _) = cpu_baseline_config1(sd)
+            ren.N_importance = 0
+            with torch.no_grad():
+                o1d, d1d = o1[None].to(dev), d1[None].to(dev)
+                ren.render({"rays_o": o1d, "rays_d": d1d})
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    g1, _ = ren.render({"rays_o": o1d, "rays_d": d1d})
+                torch.cuda.synchronize()
+                c1["hip_same_workload"] = {"rays_per_s": round(1024 * 20 / (time.perf_counter() - t1), 1),
+                                           "max_abs_rgb_diff_vs_cpu": float((g1.cpu() - c1_rgb).abs().max())}
+            ren.N_importance = 128
+            out["cpu_baseline_config1"] = c1
             # informational: the other arithmetic modes of the same path on the same frame (NOT the headline value)
             others = {}
             for pname in ("f32x", "f16"):
@@ -332,6 +448,26 @@ def main():
                                                 "f16": "fp16 activations and weights, fp32 accumulate (config 5)"}[pname]}
             net.precision = args.precision
             out["other_precisions"] = others
+
+    # BASELINE configs[2] and configs[4] on the same line (every rank takes part when N>1), AFTER the headline's timed
+    # region; a failure here is reported in its block and never costs the headline measurement
+    if args.extras and H == 800 and not args.fast_sampling:
+        del net, ren, o, d
+        extra = {}
+        try:
+            extra["training"] = {"workload": "BASELINE.json configs[2]: 4096 rays/iter per GPU, render (64+128) with "
+                                             "activation save -> MSE on fine RGB -> adjoint HIP kernels -> [gradient "
+                                             "all-reduce] -> clip 40 + Adam 5e-4 (one launch)", "n_gpus": world,
+                                 **{p: run_training(pkg, sd, dev, p, 20, 3, world, rank) for p in ("f32", "f32x")}}
+        except Exception as exc:                                 # noqa: BLE001
+            extra["training"] = {"error": f"{type(exc).__name__}: {exc}"}
+        try:
+            extra["config5"] = run_config5(pkg, sd, dev, world, rank)
+        except Exception as exc:                                 # noqa: BLE001
+            extra["config5"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if out is not None:
+            out.update(extra)
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

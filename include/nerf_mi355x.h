@@ -46,6 +46,12 @@ enum nerf_precision {
 #define NERF_N_IMPORTANCE 128
 
 int32_t nerf_abi_version(void);
+
+/* Build self-description: 0 for a product build.  Timing experiments (tools/ab_bench.py) compile kernels with
+   switches that change their numerics; such a library only builds with -DNERF_TIMING_BUILD and reports it here.
+   A binder must refuse a non-zero value (nerf_replication_amd/_lib.py does). */
+enum nerf_build_flag { NERF_BUILD_TIMING = 1, NERF_BUILD_WRONG_NUMERICS = 2 };
+int32_t nerf_build_flags(void);
 const char* nerf_last_error(void);
 
 /* Size in bytes of one packed sub-model (coarse or fine) for a precision; -1 if unknown. */
@@ -103,6 +109,17 @@ int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float*
                           int64_t n_rays, int32_t n_samples, const void* packed_bwd, const float* draw,
                           const float* save, float* gsave, float* g_t, float* const grads[24], int32_t precision,
                           void* stream);
+
+/* Point-mode twins of the two calls above, for Network.forward itself under autograd (network.py:199-258: explicit
+ * `inputs` [n_rays, n_samples, 3] and `viewdirs` [n_rays, 3] used AS GIVEN, no normalisation -- not o + d t):
+ * nerf_mlp_forward_points_save = nerf_mlp_forward + the activation store; nerf_mlp_backward_points adds the 24
+ * parameter gradients and, if `g_pts` [P,3] is given, writes d loss / d inputs (through the positional encoding).
+ * d loss / d viewdirs is not produced (no caller of the reference differentiates the ray directions). */
+int32_t nerf_mlp_forward_points_save(const float* pts, const float* viewdirs, int64_t n_rays, int32_t n_samples,
+                                     const void* packed, float* raw, float* save, int32_t precision, void* stream);
+int32_t nerf_mlp_backward_points(const float* pts, int64_t n_rays, int32_t n_samples, const void* packed_bwd,
+                                 const float* draw, const float* save, float* gsave, float* g_pts,
+                                 float* const grads[24], int32_t precision, void* stream);
 
 /* Adjoint of nerf_composite (autograd of volume_renderer.py:414-432 with :67-96): g_rgb [n,3], g_depth [n]
  * (nullable) -> g_raw [n,S,4] and, if given, g_t [n,S] (the direct dependence of the image on the sample

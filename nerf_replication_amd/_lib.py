@@ -21,6 +21,7 @@ _c = ctypes
 _F = _c.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 _PROTOS = {
     "nerf_abi_version": (_c.c_int32, []),
+    "nerf_build_flags": (_c.c_int32, []),
     "nerf_last_error": (_c.c_char_p, []),
     "nerf_packed_model_bytes": (_c.c_int64, [_c.c_int32]),
     "nerf_pack_model": (_c.c_int32, [_c.POINTER(_c.c_void_p), _F, _c.c_int32, _c.c_void_p]),
@@ -39,6 +40,9 @@ _PROTOS = {
     "nerf_pack_model_bwd": (_c.c_int32, [_c.POINTER(_c.c_void_p), _F, _c.c_int32, _c.c_void_p]),
     "nerf_mlp_backward": (_c.c_int32, [_F, _F, _F, _c.c_int64, _c.c_int64, _c.c_int32, _F, _F, _F, _F, _F,
                                        _c.POINTER(_c.c_void_p), _c.c_int32, _c.c_void_p]),
+    "nerf_mlp_forward_points_save": (_c.c_int32, [_F, _F, _c.c_int64, _c.c_int32, _F, _F, _F, _c.c_int32, _c.c_void_p]),
+    "nerf_mlp_backward_points": (_c.c_int32, [_F, _c.c_int64, _c.c_int32, _F, _F, _F, _F, _F,
+                                              _c.POINTER(_c.c_void_p), _c.c_int32, _c.c_void_p]),
     "nerf_wgrad": (_c.c_int32, [_F, _c.c_int64, _c.c_int32, _c.c_int32, _F, _c.c_int64, _c.c_int32, _c.c_int32, _F,
                                 _c.c_int64, _c.c_int32, _F, _c.c_int64, _c.c_void_p]),
     "nerf_train_save_floats": (_c.c_int64, [_c.c_int64]),
@@ -88,6 +92,9 @@ def load():
             fn.restype, fn.argtypes = res, args
         if lib.nerf_abi_version() != 1:
             raise NerfLibraryError("libnerf_mi355x.so ABI version mismatch")
+        if lib.nerf_build_flags() != 0:
+            raise NerfLibraryError(f"{LIB_PATH} is a timing build (nerf_build_flags() = {lib.nerf_build_flags()}): kernels "
+                                   "compiled with NERF_*_HACK_* switches compute wrong results; rebuild with `make -C csrc`")
         _lib = lib
     return _lib
 

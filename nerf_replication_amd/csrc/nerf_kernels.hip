@@ -15,6 +15,17 @@
 #include "nerf_mlp_bwd_f32x.hip.inc"
 #include "nerf_wgrad_bf16x3.hip.inc"
 
+// Timing-only switches (tools/ab_bench.py) change the NUMERICS of the kernels they are compiled into.  A library
+// built with any of them set must say so: it only compiles with -DNERF_TIMING_BUILD, and then reports it through
+// nerf_build_flags(), which the Python loader (and any other binder) checks -- so a stray -D can no longer produce a
+// library that passes nerf_abi_version() and computes garbage.
+#define NERF_ANY_TIMING_HACK (NERF_F32_HACK_NOLOAD || NERF_F32_HACK_NOBIAS || NERF_F32_HACK_NORELU || NERF_F32_HACK_NOPE || \
+                              NERF_F32_HACK_NOHEADS || NERF_F32_ASM_OVERRUN || NERF_F16_HACK_NOADV || NERF_F32X_HACK_NOADV || \
+                              NERF_F32X_HACK_NOPE || NERF_F32X_HACK_NOEPI)
+#if NERF_ANY_TIMING_HACK && !defined(NERF_TIMING_BUILD)
+#error "a NERF_*_HACK_* / NERF_F32_ASM_OVERRUN timing switch is set: such a library computes wrong results; build it with -DNERF_TIMING_BUILD (tools/ab_bench.py does) so that nerf_build_flags() reports it"
+#endif
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -835,6 +846,7 @@ int launch_mlp(const MlpArgs& a, bool ray_mode, int precision, hipStream_t st) {
   if (precision != NERF_PREC_F32 && precision != NERF_PREC_F16 && precision != NERF_PREC_F32X)
     return fail(NERF_ERR_UNSUPPORTED, "%s", "precision not built");
   if (a.n_points <= 0) return NERF_OK;
+  if (a.index && a.n_points > 0x7fffffffLL) return fail(NERF_ERR_INVALID_ARG, "%s", "index mode: point ids are int32");
   if (precision == NERF_PREC_F32X) {       // persistent workgroups of 4 waves, one per CU
     const long long n_tiles = (a.n_points + kXTilePts - 1) / kXTilePts;
     const unsigned blocks = (unsigned)(n_tiles < num_cus() ? n_tiles : num_cus());
@@ -872,6 +884,17 @@ inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 extern "C" {
 
 int32_t nerf_abi_version(void) { return NERF_ABI_VERSION; }
+
+int32_t nerf_build_flags(void) {
+  int32_t f = 0;
+#ifdef NERF_TIMING_BUILD
+  f |= NERF_BUILD_TIMING;
+#endif
+#if NERF_ANY_TIMING_HACK
+  f |= NERF_BUILD_WRONG_NUMERICS;
+#endif
+  return f;
+}
 const char* nerf_last_error(void) { return g_err; }
 int64_t nerf_packed_model_bytes(int32_t precision) {
   if (precision == NERF_PREC_F32) return nerf::kPackedFloats * (int64_t)sizeof(float);
@@ -1122,29 +1145,23 @@ int32_t nerf_pack_model_bwd(const float* const params[24], void* packed_bwd_v, i
 }
 
 // grads[24]: device pointers in state_dict order (nn.Linear layouts), accumulated into (caller zeroes them)
-int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float* tvals, int64_t t_ray_stride,
-                          int64_t n_rays, int32_t n_samples, const void* packed_bwd_v, const float* draw,
-                          const float* save, float* gsave, float* g_t, float* const grads[24], int32_t precision,
-                          void* stream) {
-  const float* packed_bwd = (const float*)packed_bwd_v;
-  if (n_rays < 0 || n_samples <= 0 || t_ray_stride < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_backward: bad size");
-  if (n_rays == 0) return NERF_OK;
-  if (!rays_o || !rays_d || !tvals || !packed_bwd || !draw || !save || !gsave || !grads)
-    return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_backward: null argument");
-  for (int i = 0; i < 24; ++i) if (!grads[i]) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_backward: null gradient pointer");
-  const long long P = n_rays * n_samples;
-  BwdArgs a;
-  a.rays_o = rays_o; a.rays_d = rays_d; a.tvals = tvals; a.t_ray_stride = t_ray_stride; a.n_points = P; a.n_samples = n_samples;
-  a.packed_bwd = packed_bwd; a.draw = draw; a.save = save; a.gsave = gsave; a.g_t = g_t;
+// shared by the ray-mode and the point-mode entry: data-gradient chain, then the weight / bias gradients
+static int32_t mlp_backward_impl(const BwdArgs& a, bool pts_mode, float* const grads[24], int32_t precision, void* stream) {
+  const long long P = a.n_points;
+  const float* draw = a.draw; const float* save = a.save; float* gsave = a.gsave;
   int rc;
   if (precision == NERF_PREC_F32X) {
     const long long n_tiles = (P + kXTilePts - 1) / kXTilePts;
     const unsigned blocks = (unsigned)(n_tiles < num_cus() ? n_tiles : num_cus());
-    hipLaunchKernelGGL(nerf_mlp_bwd_f32x_kernel, dim3(blocks), dim3(kXThreads), 0, (hipStream_t)stream, a);
+    if (pts_mode) hipLaunchKernelGGL(nerf_mlp_bwd_f32x_kernel<true>, dim3(blocks), dim3(kXThreads), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(nerf_mlp_bwd_f32x_kernel<false>, dim3(blocks), dim3(kXThreads), 0, (hipStream_t)stream, a);
     rc = check_launch("nerf_mlp_bwd_f32x_kernel");
   } else if (precision == NERF_PREC_F32) {
     const long long tiles = (P + nerf::kTilePts - 1) / nerf::kTilePts;
-    hipLaunchKernelGGL(nerf_mlp_bwd_f32_kernel, dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, a);       // barrier-free: one-wave workgroups
+    if (tiles > 0x7fffffffLL) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_backward: too many points for one launch");
+    // barrier-free: one-wave workgroups
+    if (pts_mode) hipLaunchKernelGGL(nerf_mlp_bwd_f32_kernel<true>, dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(nerf_mlp_bwd_f32_kernel<false>, dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, a);
     rc = check_launch("nerf_mlp_bwd_f32_kernel");
   } else return fail(NERF_ERR_UNSUPPORTED, "%s", "nerf_mlp_backward: f32 or f32x only");
   if (rc) return rc;
@@ -1199,7 +1216,8 @@ int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float*
       if (l == 5) job(GZ(5), H(4), grads[10], 319, 63, nullptr);
       else job(GZ(l), H(l - 1), grads[2 * l], 256, 0, grads[2 * l + 1]);
     }
-    const long long slices = num_cus() / wb.n_jobs;
+    long long slices = num_cus() / wb.n_jobs;
+    if (slices < 1) slices = 1;                       // a device with fewer CUs than jobs still gets a non-empty grid
     hipLaunchKernelGGL(nerf_wgrad256_f32_asm_kernel, dim3((unsigned)(slices * wb.n_jobs)), dim3(256), 0, (hipStream_t)stream, wb);
     rc = check_launch("nerf_wgrad256_f32_asm_kernel");
     if (rc) return rc;
@@ -1212,6 +1230,35 @@ int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float*
   }
 #undef WG
   return NERF_OK;
+}
+
+int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float* tvals, int64_t t_ray_stride,
+                          int64_t n_rays, int32_t n_samples, const void* packed_bwd_v, const float* draw,
+                          const float* save, float* gsave, float* g_t, float* const grads[24], int32_t precision,
+                          void* stream) {
+  if (n_rays < 0 || n_samples <= 0 || t_ray_stride < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_backward: bad size");
+  if (n_rays == 0) return NERF_OK;
+  if (!rays_o || !rays_d || !tvals || !packed_bwd_v || !draw || !save || !gsave || !grads)
+    return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_backward: null argument");
+  for (int i = 0; i < 24; ++i) if (!grads[i]) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_backward: null gradient pointer");
+  BwdArgs a{};
+  a.rays_o = rays_o; a.rays_d = rays_d; a.tvals = tvals; a.t_ray_stride = t_ray_stride; a.n_points = n_rays * n_samples;
+  a.n_samples = n_samples; a.packed_bwd = (const float*)packed_bwd_v; a.draw = draw; a.save = save; a.gsave = gsave; a.g_t = g_t;
+  return mlp_backward_impl(a, false, grads, precision, stream);
+}
+
+int32_t nerf_mlp_backward_points(const float* pts, int64_t n_rays, int32_t n_samples, const void* packed_bwd_v,
+                                 const float* draw, const float* save, float* gsave, float* g_pts,
+                                 float* const grads[24], int32_t precision, void* stream) {
+  if (n_rays < 0 || n_samples <= 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_backward_points: bad size");
+  if (n_rays == 0) return NERF_OK;
+  if (!pts || !packed_bwd_v || !draw || !save || !gsave || !grads)
+    return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_backward_points: null argument");
+  for (int i = 0; i < 24; ++i) if (!grads[i]) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_backward_points: null gradient pointer");
+  BwdArgs a{};
+  a.pts = pts; a.g_x = g_pts; a.n_points = n_rays * n_samples; a.n_samples = n_samples;
+  a.packed_bwd = (const float*)packed_bwd_v; a.draw = draw; a.save = save; a.gsave = gsave;
+  return mlp_backward_impl(a, true, grads, precision, stream);
 }
 
 int64_t nerf_train_save_floats(int64_t n_points) { return n_points < 0 ? -1 : TrainSave::floats(n_points); }
@@ -1233,8 +1280,30 @@ int32_t nerf_mlp_forward_rays_save(const float* rays_o, const float* rays_d, con
   }
   if (precision != NERF_PREC_F32) return fail(NERF_ERR_UNSUPPORTED, "%s", "nerf_mlp_forward_rays_save: f32 or f32x only");
   const long long tiles = (a.n_points + nerf::kTilePts - 1) / nerf::kTilePts;
+  if (tiles > 0x7fffffffLL) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_rays_save: too many points for one launch");
   hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, true>), dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, a);   // barrier-free: one-wave workgroups
   return check_launch("nerf_mlp_f32_kernel<save>");
+}
+
+int32_t nerf_mlp_forward_points_save(const float* pts, const float* viewdirs, int64_t n_rays, int32_t n_samples,
+                                     const void* packed, float* raw, float* save, int32_t precision, void* stream) {
+  if (n_rays < 0 || n_samples <= 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_points_save: bad size");
+  if (n_rays == 0) return NERF_OK;
+  if (!pts || !viewdirs || !packed || !raw || !save) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_points_save: null argument");
+  MlpArgs a{};
+  a.pts = pts; a.viewdirs = viewdirs; a.n_points = n_rays * n_samples; a.n_samples = n_samples;
+  a.packed = (const float*)packed; a.raw = raw; a.save = save;
+  if (precision == NERF_PREC_F32X) {
+    const long long n_tiles = (a.n_points + kXTilePts - 1) / kXTilePts;
+    const unsigned blocks = (unsigned)(n_tiles < num_cus() ? n_tiles : num_cus());
+    hipLaunchKernelGGL((nerf_mlp_f32x_kernel<false, true>), dim3(blocks), dim3(kXThreads), 0, (hipStream_t)stream, a);
+    return check_launch("nerf_mlp_f32x_kernel<points,save>");
+  }
+  if (precision != NERF_PREC_F32) return fail(NERF_ERR_UNSUPPORTED, "%s", "nerf_mlp_forward_points_save: f32 or f32x only");
+  const long long tiles = (a.n_points + nerf::kTilePts - 1) / nerf::kTilePts;
+  if (tiles > 0x7fffffffLL) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_points_save: too many points for one launch");
+  hipLaunchKernelGGL((nerf_mlp_f32_kernel<false, true>), dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, a);
+  return check_launch("nerf_mlp_f32_kernel<points,save>");
 }
 
 int32_t nerf_image_ssim(const float* pred, const float* gt, int32_t H, int32_t W, double* sum1, void* stream) {
@@ -1273,6 +1342,10 @@ int32_t nerf_render_forward(const float* rays_o, const float* rays_d, int64_t n_
     return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_render_forward: null argument");
   if (workspace_bytes < nerf_render_workspace_bytes(n_rays, n_importance, fast_sampling))
     return fail(NERF_ERR_WORKSPACE, "%s", "nerf_render_forward: workspace too small");
+  // the masked fine pass addresses (ray, sample) pairs by 32-bit ids (nerf_compact_kernel, MlpArgs::index)
+  if (fast_sampling && n_importance && n_rays > (int64_t)0x7fffffff / (NERF_N_SAMPLES + NERF_N_IMPORTANCE))
+    return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_render_forward: fast_sampling handles at most 11 184 810 rays per call "
+                                            "(n_rays * 192 point ids must fit in int32): split the frame");
   char* ws = (char*)workspace;
   float* raw_c = (float*)ws;
   int rc = nerf_mlp_forward_rays(rays_o, rays_d, t_coarse, 0, n_rays, NERF_N_SAMPLES, packed_coarse, raw_c, precision, stream);

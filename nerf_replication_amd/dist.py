@@ -17,15 +17,25 @@ def shard_bounds(n_rays: int, rank: int, world: int):
     return lo, min(lo + per, n_rays), per
 
 
-def render_sharded(renderer, rays_o, rays_d, group=None):
-    """rays_o, rays_d: the FULL frame [N,3] (or this rank's view of it) on the rank's device.
-    Each rank renders only its shard, then one all_gather returns the full (rgb [N,3], depth [N])
-    on every rank.  With world_size 1 this is exactly renderer.render."""
+def render_shard(renderer, rays_o_local, rays_d_local, n_total, group=None, events=None):
+    """This rank's contiguous shard ONLY: rays_*_local [hi-lo,3] are rows [lo,hi) = shard_bounds(n_total, rank, world)
+    of the frame (e.g. from generate_rays(pixel_begin=lo, n_pixels=hi-lo)); no rank ever materialises the whole
+    frame's rays.  Renders them, then one all_gather returns the full (rgb [n_total,3], depth [n_total]) on every
+    rank.  `events`, if a list, receives a (start, end) pair of device events around the local render (CUDA only)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    n = rays_o.shape[0]
-    lo, hi, per = shard_bounds(n, rank, world)
-    rgb, depth = renderer.render({"rays_o": rays_o[lo:hi][None], "rays_d": rays_d[lo:hi][None]})
+    lo, hi, per = shard_bounds(n_total, rank, world)
+    if rays_o_local.shape[0] != hi - lo:
+        raise ValueError(f"rank {rank}/{world}: expected {hi - lo} local rays (rows [{lo},{hi}) of {n_total}), "
+                         f"got {rays_o_local.shape[0]}")
+    timed = events is not None and rays_o_local.is_cuda
+    if timed:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    rgb, depth = renderer.render({"rays_o": rays_o_local[None], "rays_d": rays_d_local[None]})
+    if timed:
+        ev[1].record()
+        events.append(ev)
     if world == 1:
         return rgb, depth
     packed = torch.zeros((per, 4), dtype=torch.float32, device=rgb.device)
@@ -33,7 +43,17 @@ def render_sharded(renderer, rays_o, rays_d, group=None):
     packed[: hi - lo, 3] = depth
     full = torch.empty((world * per, 4), dtype=torch.float32, device=rgb.device)
     dist.all_gather_into_tensor(full, packed, group=group)
-    return full[:n, :3].contiguous(), full[:n, 3].contiguous()
+    return full[:n_total, :3].contiguous(), full[:n_total, 3].contiguous()
+
+
+def render_sharded(renderer, rays_o, rays_d, group=None):
+    """Convenience over render_shard for a caller that already holds the FULL frame's rays [N,3] on every rank:
+    slices this rank's rows and gathers.  With world_size 1 this is exactly renderer.render."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = rays_o.shape[0]
+    lo, hi, _ = shard_bounds(n, rank, world)
+    return render_shard(renderer, rays_o[lo:hi], rays_d[lo:hi], n, group)
 
 
 def _shared_flat_view(grads):

@@ -126,10 +126,19 @@ class Network(nn.Module):
 
     def forward(self, inputs, viewdirs, valid_mask, model=""):
         """inputs [n,s,3], viewdirs [n,3], valid_mask BoolTensor[n,s] | None, model "" | "fine"
-        -> raw [n,s,4] = (r,g,b,sigma) pre-activation (network.py:199-258)."""
-        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("backward through the fused HIP MLP is not built yet: call under "
-                                      "torch.no_grad() or .eval() (SURVEY.md section 8, config 3 is a later row)")
+        -> raw [n,s,4] = (r,g,b,sigma) pre-activation (network.py:199-258).
+
+        Differentiable like the reference's: with autograd on and either `inputs.requires_grad` or a `.train()` network
+        whose parameters require grad, the forward runs the SAVE-mode fused kernel and backward() the adjoint HIP
+        kernels (nerf_mlp_backward_points): gradients w.r.t. the 24 tensors of the selected sub-model and w.r.t.
+        `inputs`.  (`viewdirs` are constants of the rays in every caller of the reference; their gradient is not built.)"""
+        sub = self.model_fine if model == "fine" else self.model
+        if torch.is_grad_enabled() and (inputs.requires_grad or
+                                        (self.training and any(p.requires_grad for p in sub.parameters()))):
+            if viewdirs.requires_grad:
+                raise NotImplementedError("d raw / d viewdirs is not built (no caller of the reference differentiates the "
+                                          "ray directions); detach viewdirs")
+            return self._forward_with_grad(inputs, viewdirs, valid_mask, model, sub)
         lib = _lib.load()
         dev = inputs.device
         n, s = inputs.shape[0], inputs.shape[1]
@@ -155,6 +164,75 @@ class Network(nn.Module):
         out = torch.zeros((n * s, 4), dtype=torch.float32, device=dev)
         out[flat] = raw_valid.reshape(m, 4)
         return out.reshape(n, s, 4)
+
+    def _forward_with_grad(self, inputs, viewdirs, valid_mask, model, sub):
+        if self.precision not in ("f32", "f32x"):
+            raise NotImplementedError("training runs on the fp32-accurate paths: precision 'f32' or 'f32x'")
+        n, s = inputs.shape[0], inputs.shape[1]
+        params = tuple(sub.ordered_params())
+        if valid_mask is None:
+            return _MlpFunction.apply(self, model, inputs.to(torch.float32), viewdirs.detach().to(torch.float32), *params)
+        # masked (network.py:207-214, :238-253): the valid points as m one-sample rays; the scatter back into zeros is
+        # index plumbing whose adjoint (a gather) torch provides
+        flat = valid_mask.reshape(-1)
+        pts = inputs.to(torch.float32).reshape(-1, 3)[flat][:, None, :]
+        dirs = viewdirs.detach().to(torch.float32)[:, None].expand(n, s, 3).reshape(-1, 3)[flat]
+        out = torch.zeros((n * s, 4), dtype=torch.float32, device=inputs.device)
+        if pts.shape[0] > 0:
+            out = out.index_put((flat.nonzero(as_tuple=True)[0],), _MlpFunction.apply(self, model, pts, dirs, *params)[:, 0])
+        return out.reshape(n, s, 4)
+
+
+class _MlpFunction(torch.autograd.Function):
+    """Network.forward (network.py:199-258) under autograd: SAVE-mode fused forward, adjoint HIP kernels backward.
+    torch.autograd only routes the gradients; every number comes out of a HIP kernel."""
+
+    @staticmethod
+    def forward(ctx, net, model, inputs, viewdirs, *params):
+        lib = _lib.load()
+        dev = inputs.device
+        n, s = inputs.shape[0], inputs.shape[1]
+        prec = _lib.PRECISIONS[net.precision]
+        pts = inputs.detach().contiguous()
+        dirs = viewdirs.detach().contiguous()
+        raw = torch.empty((n, s, 4), dtype=torch.float32, device=dev)
+        save = torch.empty(max(1, int(lib.nerf_train_save_floats(n * s))), dtype=torch.float32, device=dev)
+        if n * s > 0:
+            packed = net.packed(model)
+            with torch.cuda.device(dev):
+                _lib.check(lib.nerf_mlp_forward_points_save(_lib.ptr(pts), _lib.ptr(dirs), n, s, packed.data_ptr(),
+                                                            _lib.ptr(raw), _lib.ptr(save), prec, _lib.stream_of(dev)),
+                           "nerf_mlp_forward_points_save")
+        ctx.prec, ctx.shape, ctx.params = prec, (n, s), params
+        ctx.save_for_backward(pts, save)
+        return raw
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        lib = _lib.load()
+        pts, save = ctx.saved_tensors
+        params, (n, s), prec = ctx.params, ctx.shape, ctx.prec
+        dev = pts.device
+        st = _lib.stream_of(dev)
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+        grads, off = [], 0
+        for p in params:
+            grads.append(flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        g_pts = torch.zeros((n, s, 3), dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
+        if n * s > 0:
+            g_raw = g_raw.contiguous().to(torch.float32)
+            srcs = [p.detach().contiguous() for p in params]
+            arr = (ctypes.c_void_p * 24)(*[t.data_ptr() for t in srcs])
+            garr = (ctypes.c_void_p * 24)(*[g.data_ptr() for g in grads])
+            with torch.cuda.device(dev):
+                pk_b = torch.empty(int(lib.nerf_packed_bwd_bytes(prec)), dtype=torch.uint8, device=dev)
+                _lib.check(lib.nerf_pack_model_bwd(arr, pk_b.data_ptr(), prec, st), "nerf_pack_model_bwd")
+                gsave = torch.empty(int(lib.nerf_train_grad_floats(n * s)), dtype=torch.float32, device=dev)
+                _lib.check(lib.nerf_mlp_backward_points(_lib.ptr(pts), n, s, pk_b.data_ptr(), _lib.ptr(g_raw), _lib.ptr(save),
+                                                        _lib.ptr(gsave), None if g_pts is None else _lib.ptr(g_pts), garr,
+                                                        prec, st), "nerf_mlp_backward_points")
+        return (None, None, g_pts, None) + tuple(g.to(p.dtype) if p.requires_grad else None for g, p in zip(grads, params))
 
 
 def positional_encoding(x, n_freqs):

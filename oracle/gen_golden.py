@@ -37,12 +37,7 @@ def import_reference():
     return Network, Renderer
 
 
-def seeded_rays(n, seed):
-    g = torch.Generator().manual_seed(seed)
-    o = torch.tensor([0.0, 0.0, 4.0]).expand(n, 3).contiguous()
-    d = torch.randn(n, 3, generator=g) * 0.2 + torch.tensor([0.0, 0.0, -1.0])
-    d = d / d.norm(dim=-1, keepdim=True)
-    return o, d.contiguous()
+seeded_rays = orc.seeded_rays
 
 
 def npz(name, **arrs):
@@ -166,6 +161,8 @@ def main():
             rgb=rgb_m, depth=dep_m, pin_rays_o=po, pin_rays_d=pd, pin_rgb=prgb_m, pin_depth=pdep_m,
             valid_fine_thr002=vmask2, rgb_thr002=rgb_m2, depth_thr002=dep_m2)
 
+    family_fixtures(net, ren, sd)
+
     # (8) autograd fixture: MSE on fine RGB, grads of all 48 tensors for a 64-ray step
     net.train()
     o, d = seeded_rays(64, 21)
@@ -178,5 +175,49 @@ def main():
     npz("autograd.npz", rays_o=o, rays_d=d, gt=gt, rgb=rgb, depth=dep, loss=loss, **grads)
 
 
+def family_fixtures(net, ren, base_sd):
+    """(10) Parity scenes beyond the benign band-limited field (round-1 VERDICT "Weak 2"): for each weight family of
+    oracle.WEIGHT_FAMILIES (exact elementwise transforms of the base checkpoint) the REAL reference renders 512 seeded
+    rays and 512 pinhole rays; the merged sample depths are re-derived with the reference's own methods so the GPU
+    tests can attribute any per-ray deviation to moved samples (inverse-CDF discontinuities)."""
+    ids = torch.from_numpy(np.random.default_rng(1).choice(800 * 800, 512, replace=False))
+    sets = {"seed": orc.seeded_rays(512, 31), "pin": orc.pinhole_rays(800, 800, orc.camera_pose(55.0), pixel_ids=ids)}
+    for fam in orc.WEIGHT_FAMILIES:
+        net.load_state_dict(orc.weight_family(base_sd, fam), strict=True)
+        rec = {}
+        with torch.no_grad():
+            for tag, (o, d) in sets.items():
+                t_c, pts_c = ren.stratified_sample_points_from_rays(o, d, N_samples=64, perturb=False)
+                vd = d / torch.norm(d, dim=-1, keepdim=True)
+                raw_c = net.forward(pts_c, vd, None, model="")
+                pts_f, t_f, vm = ren.fine_sample_points(torch.relu(raw_c[..., 3]), o, d, t_c, 128, 64, 0.25)
+                assert vm is None
+                t_sorted, _ = torch.sort(torch.cat([t_c, t_f], 1), dim=-1)
+                rgb, dep = ren.render({"rays_o": o[None], "rays_d": d[None]})
+                rec.update({f"{tag}_rays_o": o, f"{tag}_rays_d": d, f"{tag}_sigma_coarse_raw": raw_c[..., 3],
+                            f"{tag}_t_sorted": t_sorted, f"{tag}_rgb": rgb, f"{tag}_depth": dep})
+        npz(f"render_family_{fam}.npz", **rec)
+    net.load_state_dict(base_sd, strict=True)
+
+
+def families_only():
+    """python oracle/gen_golden.py --families : only the family fixtures, from the COMMITTED base checkpoint."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    Network, Renderer = import_reference()
+    ck = torch.load(os.path.join(OUT, "synthetic_ckpt.pth"), weights_only=True)
+    sd = {k: ck["net"][k] for k in orc.state_dict_keys()}
+    net = Network()
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    ren = Renderer(net)
+    ren.device = torch.device("cpu")
+    family_fixtures(net, ren, sd)
+
+
 if __name__ == "__main__":
-    main()
+    if "--families" in sys.argv:
+        sys.argv.remove("--families")
+        families_only()
+    else:
+        main()

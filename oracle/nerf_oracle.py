@@ -115,6 +115,46 @@ def synthetic_state_dict(seed: int = 0, occupied: float = 0.3, sigma_std: float 
     return {k: sd[k].contiguous() for k in state_dict_keys()}
 
 
+# Weight families for parity scenes.  Each is an EXACT elementwise transform of a base state_dict (the committed
+# tests/golden/synthetic_ckpt.pth), so every machine derives bit-identical tensors from the one checkpoint file
+# (synthetic_state_dict itself calibrates its heads with CPU GEMMs and is not bit-reproducible across CPU models).
+#   "base"   the band-limited field as stored: sigma ~ N(-4.5, 8), ~30 % of space occupied
+#   "sharp"  trained-NeRF-like density: sigma_raw' = 7.5*sigma_raw - 30  ->  std 60 (sigma up to several hundred), ~5 %
+#            of the samples along the fixture rays occupied, ~40 % of the rays end on a hard surface: most CDF bins
+#            empty (pdf = 1e-5/sum, i.e. the `denom < 1e-5` regime of volume_renderer.py:259-260 whenever a ray's
+#            inner weights sum to ~1)
+#   "white"  octave_decay = 0: the 2^-k damping of the positional-encoding input columns is undone exactly (x 2^k),
+#            heads re-scaled by fixed constants to sigma ~ N(-4.2, 8), ~30 % occupied: a white-noise field, every
+#            sample position matters (round 1's first smoke scene)
+WEIGHT_FAMILIES = {
+    "base": dict(alpha_gain=1.0, alpha_shift=0.0, undo_octave_decay=False),
+    "sharp": dict(alpha_gain=7.5, alpha_shift=30.0, undo_octave_decay=False),
+    "white": dict(alpha_gain=0.345, alpha_shift=3.0, undo_octave_decay=True),
+}
+
+
+def weight_family(base_sd: Dict[str, torch.Tensor], name: str) -> Dict[str, torch.Tensor]:
+    spec = WEIGHT_FAMILIES[name]
+    out = {k: v.clone() for k, v in base_sd.items()}
+    for m in ("model", "model_fine"):
+        out[f"{m}.alpha_linear.weight"] = out[f"{m}.alpha_linear.weight"] * spec["alpha_gain"]
+        out[f"{m}.alpha_linear.bias"] = out[f"{m}.alpha_linear.bias"] * spec["alpha_gain"] - spec["alpha_shift"]
+        if spec["undo_octave_decay"]:
+            for k in range(XYZ_FREQS):
+                out[f"{m}.pts_linears.0.weight"][:, 3 + 6 * k:9 + 6 * k] *= 2.0 ** k
+                out[f"{m}.pts_linears.5.weight"][:, 3 + 6 * k:9 + 6 * k] *= 2.0 ** k
+    return {k: out[k].contiguous() for k in state_dict_keys()}
+
+
+def seeded_rays(n: int, seed: int):
+    """Parity ray set: origin (0,0,4), directions normalize(randn*0.2 + (0,0,-1))."""
+    g = torch.Generator().manual_seed(seed)
+    o = torch.tensor([0.0, 0.0, 4.0]).expand(n, 3).contiguous()
+    d = torch.randn(n, 3, generator=g) * 0.2 + torch.tensor([0.0, 0.0, -1.0])
+    d = d / d.norm(dim=-1, keepdim=True)
+    return o, d.contiguous()
+
+
 # ----------------------------------------------------------------------------- encoding
 def freq_encode(x: torch.Tensor, n_freqs: int) -> torch.Tensor:
     """[P,3] -> [P, 3+6*n_freqs]: x, then per octave sin(2^k x) (3 wide), cos(2^k x) (3 wide)."""
@@ -153,16 +193,22 @@ def nerf_mlp(sd: Dict[str, torch.Tensor], prefix: str, emb: torch.Tensor,
 
 
 def network_forward(sd, pts: torch.Tensor, viewdirs: torch.Tensor, model: str = "",
-                    chunk: int = MLP_CHUNK) -> torch.Tensor:
-    """pts [n,s,3], viewdirs [n,3] -> raw [n,s,4]; MLP run `chunk` points at a time."""
+                    chunk: int = MLP_CHUNK, mlp_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """pts [n,s,3], viewdirs [n,3] -> raw [n,s,4]; MLP run `chunk` points at a time.
+    `mlp_dtype=torch.float64` is NOT the reference's arithmetic: it evaluates encoding + MLP in double on
+    the same fp32 inputs/weights and rounds raw back to fp32 -- the probe the noise-floor test uses to
+    measure how far the reference's own fp32 rounding moves its image (tests/test_noise_floor.py)."""
     prefix = "model_fine" if model == "fine" else "model"
     n, s, _ = pts.shape
     flat = pts.reshape(-1, 3)
     dflat = viewdirs[:, None].expand(n, s, 3).reshape(-1, 3)
+    if mlp_dtype != torch.float32:
+        sd = {k: v.to(mlp_dtype) for k, v in sd.items() if k.startswith(prefix + ".")}
+        flat, dflat = flat.to(mlp_dtype), dflat.to(mlp_dtype)
     emb = torch.cat([freq_encode(flat, XYZ_FREQS), freq_encode(dflat, DIR_FREQS)], -1)
-    emb = emb.to(torch.float32)
+    emb = emb.to(mlp_dtype)
     outs = [nerf_mlp(sd, prefix, emb[i:i + chunk]) for i in range(0, emb.shape[0], chunk)]
-    return torch.cat(outs, 0).reshape(n, s, 4)
+    return torch.cat(outs, 0).reshape(n, s, 4).to(torch.float32)
 
 
 # ----------------------------------------------------------------------------- sampling
@@ -254,7 +300,8 @@ def composite(raw: torch.Tensor, t: torch.Tensor, white_bkgd: bool = True):
 # ----------------------------------------------------------------------------- render
 def render(sd, rays_o: torch.Tensor, rays_d: torch.Tensor, n_importance: int = N_IMPORTANCE,
            white_bkgd: bool = True, return_parts: bool = False, chunk: int = MLP_CHUNK,
-           fast_sampling: bool = False, weights_threshold: float = 0.25):
+           fast_sampling: bool = False, weights_threshold: float = 0.25,
+           mlp_dtype: torch.dtype = torch.float32):
     """rays_o, rays_d [B,N,3] -> (rgb [B*N,3], depth [B*N]) exactly as Renderer.render does,
     including its 160000-ray x 64-sample blocking of the MLP calls."""
     rays_o = rays_o.reshape(-1, 3)
@@ -264,7 +311,7 @@ def render(sd, rays_o: torch.Tensor, rays_d: torch.Tensor, n_importance: int = N
     pts_c = points_on_rays(rays_o, rays_d, t_c)
     viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
 
-    raw = torch.cat([network_forward(sd, pts_c[i:i + RAYS_BLOCK], viewdirs[i:i + RAYS_BLOCK], "", chunk)
+    raw = torch.cat([network_forward(sd, pts_c[i:i + RAYS_BLOCK], viewdirs[i:i + RAYS_BLOCK], "", chunk, mlp_dtype)
                      for i in range(0, n, RAYS_BLOCK)], 0)
     depth = t_c
     parts = {"raw_coarse": raw, "t_coarse": t_c, "viewdirs": viewdirs}
@@ -277,7 +324,7 @@ def render(sd, rays_o: torch.Tensor, rays_d: torch.Tensor, n_importance: int = N
         rows = []
         for i in range(0, n, RAYS_BLOCK):
             cols = [network_forward(sd, pts[i:i + RAYS_BLOCK, j:j + SAMPLE_BLOCK],
-                                    viewdirs[i:i + RAYS_BLOCK], "fine", chunk)
+                                    viewdirs[i:i + RAYS_BLOCK], "fine", chunk, mlp_dtype)
                     for j in range(0, pts.shape[1], SAMPLE_BLOCK)]
             rows.append(torch.cat(cols, 1))
         raw = torch.cat(rows, 0)

@@ -1,13 +1,17 @@
 """-m gpu: the HIP path, called through the C ABI (ctypes), against the CPU oracle and the golden
 vectors the real reference produced.  Tolerances (fp32 path):
     raw MLP outputs     |d| <= 2e-5 * max|ref| per channel  (different fp32 summation order)
-    final image         PSNR >= 70 dB, 99 % of rays |d rgb| <= 1e-4 and |d depth| <= 1e-3,
-                        every ray |d rgb| <= 2e-3, |d depth| <= 2e-2
-The image bound is two-tier because the reference algorithm is discontinuous in its own rounding:
-an inverse-CDF sample jumps by up to one bin when `denom < 1e-5` flips (volume_renderer.py:259-260)
-or a searchsorted index flips next to an empty bin.  Evaluating the reference's MLP in float64
-instead of float32 moves its own output by max 1.2e-4 rgb / 5e-4 depth on this scene (PSNR 115 dB,
-DESIGN.md "Parity tolerance"), so a per-ray max of 1e-4 cannot be met even by the reference itself.
+    final image         PSNR >= 70 dB, 99 % of rays |d rgb| <= 1e-4 and |d depth| <= 1e-3 (SURVEY 8c's figures), and
+                        ATTRIBUTION of everything above that (test_family_parity_attributed): with the reference's
+                        own sample depths fed to the HIP fine pass + compositing EVERY ray is inside 1e-4 / 1e-3
+The image bound cannot be a flat per-ray maximum because the reference algorithm is discontinuous / ill-conditioned
+in its own rounding: an inverse-CDF sample jumps by up to one bin when `denom < 1e-5` flips
+(volume_renderer.py:259-260) or a searchsorted index flips next to an empty bin, and inside a nearly empty bin
+the division by `denom` ~ 1e-5 amplifies a 1e-7 cdf rounding to ~1e-3 in depth.  tests/test_noise_floor.py measures
+what that does to the reference against itself (fp64 MLP probe, 3072 rays): max 1.4e-4 / 5.8e-4 on the band-limited
+scene, 3.5e-5 / 5.9e-4 on the sharp-density scene, 1.8e-2 / 4.9e-2 on the white-noise scene (19 rays over).  So: stage tests on identical
+inputs are tight, the end-to-end image is bounded in the bulk + by attribution, and the hard per-ray maximum is
+pinned per scene family at ~3x the value measured on the GPU (kept in profiles/parity_r02.json, not just printed).
 Bit-exact where the arithmetic is order-free (point construction, merge of sorted depths,
 ray-permutation / chunk invariance).
 """
@@ -17,25 +21,43 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN
+from conftest import GOLDEN, parity_record
 import pack_reference
 
 pytestmark = pytest.mark.gpu
 
 RAW_RTOL = 2e-5
+EPS_RGB, EPS_DEP = 1e-4, 1e-3            # SURVEY 8c per-ray image tolerance
+# hard per-ray maxima: ~3x the largest value measured on the MI355X for that scene family (profiles/parity_r02.json)
+HARD_MAX = {"base": (8e-4, 3e-3), "sharp": (1e-4, 1e-3), "white": (6e-2, 2.5e-1)}
+# rays allowed outside 1e-4 / 1e-3: base / sharp 1 % (measured <= 1 of 512), white-noise field 3 % (measured 7 of 512;
+# the reference against its own fp64-MLP self: 19 of 3072, tests/test_noise_floor.py)
+MAX_OVER_FRAC = {"base": 0.01, "sharp": 0.01, "white": 0.03}
 
 
-def assert_image_close(oracle, rgb, dep, ref_rgb, ref_dep, max_rgb=2e-3, max_dep=2e-2):
+def image_stats(oracle, rgb, dep, ref_rgb, ref_dep):
     rgb, dep = rgb.detach().cpu(), dep.detach().cpu()
     e_rgb = (rgb - ref_rgb).abs().max(-1).values
     e_dep = (dep - ref_dep).abs()
-    psnr = oracle.psnr(rgb, ref_rgb)
-    msg = f"PSNR {psnr:.1f} dB, rgb max {e_rgb.max():.2e} q99 {torch.quantile(e_rgb, 0.99):.2e}, " \
-          f"depth max {e_dep.max():.2e} q99 {torch.quantile(e_dep, 0.99):.2e}"
-    print(msg)
-    assert psnr >= 70.0, msg
-    assert torch.quantile(e_rgb, 0.99) <= 1e-4 and torch.quantile(e_dep, 0.99) <= 1e-3, msg
-    assert e_rgb.max() <= max_rgb and e_dep.max() <= max_dep, msg
+    over = (e_rgb > EPS_RGB) | (e_dep > EPS_DEP)
+    st = dict(n_rays=int(e_rgb.numel()), psnr_db=round(oracle.psnr(rgb, ref_rgb), 2),
+              rgb_max=e_rgb.max().item(), rgb_q99=torch.quantile(e_rgb, 0.99).item(),
+              depth_max=e_dep.max().item(), depth_q99=torch.quantile(e_dep, 0.99).item(),
+              rays_over_tolerance=int(over.sum()))
+    return st, over
+
+
+def assert_image_close(oracle, rgb, dep, ref_rgb, ref_dep, max_rgb=None, max_dep=None, family="base", name=None):
+    st, _ = image_stats(oracle, rgb, dep, ref_rgb, ref_dep)
+    if name is not None:
+        parity_record("image_vs_reference", name, st)
+    print(name or "image", st)
+    max_rgb = HARD_MAX[family][0] if max_rgb is None else max_rgb
+    max_dep = HARD_MAX[family][1] if max_dep is None else max_dep
+    assert st["psnr_db"] >= 70.0, st
+    assert st["rgb_q99"] <= EPS_RGB and st["depth_q99"] <= EPS_DEP, st
+    assert st["rgb_max"] <= max_rgb and st["depth_max"] <= max_dep, st
+    return st
 
 
 @pytest.fixture(scope="module")
@@ -172,7 +194,13 @@ def test_fine_sampling_stage(amd, golden):
     # amplified where a u lands in an almost-empty CDF bin)
     # (a flip of `denom < 1e-5` or of a searchsorted index next to an empty bin moves one sample by
     # up to a bin width 4/63 -- the reference's own discontinuity, see module docstring)
-    assert d.max() <= 4.0 / 63 and (d <= 2e-5).float().mean() >= 0.995, (d.max().item(), (d <= 2e-5).float().mean().item())
+    parity_record("stage_fine_sampling_identical_inputs", "sampling.npz/256x128", {
+        "max_move": d.max().item(), "frac_within_2e-5": (d <= 2e-5).float().mean().item(),
+        "samples_moved_gt_1e-4": int((d > 1e-4).sum()), "samples_moved_gt_1e-3": int((d > 1e-3).sum()),
+        "n_samples": int(d.numel())})
+    # measured on the MI355X: 99.97 % within 2e-5, 6 of 32 768 samples moved by more than 1e-3 (flips)
+    assert d.max() <= 4.0 / 63 and (d <= 2e-5).float().mean() >= 0.999 and int((d > 1e-3).sum()) <= 33, \
+        (d.max().item(), (d <= 2e-5).float().mean().item(), int((d > 1e-3).sum()))
     assert torch.equal(tf[:, -1], g["t_fine"][:, -1])                 # F7 tail collapse onto bins[61]
     # merged output is exactly the sort of (coarse U own fine depths)
     want, _ = torch.sort(torch.cat([g["t_coarse"], tf], 1), dim=-1)
@@ -226,19 +254,102 @@ def test_render_golden(amd, net, golden, oracle):
     g = golden("render.npz")
     rgb, dep = _render(amd, net, g["rays_o"][None], g["rays_d"][None])
     assert rgb.shape == (256, 3) and dep.shape == (256,) and rgb.is_cuda
-    assert_image_close(oracle, rgb, dep, g["rgb_128"], g["depth_128"])
+    assert_image_close(oracle, rgb, dep, g["rgb_128"], g["depth_128"], name="render.npz/seeded256/f32")
     rgb0, dep0 = _render(amd, net, g["rays_o"][None], g["rays_d"][None], n_importance=0)
-    assert (rgb0.cpu() - g["rgb_0"]).abs().max() <= 2e-5          # no resampling: continuous, tight
-    assert (dep0.cpu() - g["depth_0"]).abs().max() <= 1e-4
+    e0, z0 = (rgb0.cpu() - g["rgb_0"]).abs().max().item(), (dep0.cpu() - g["depth_0"]).abs().max().item()
+    parity_record("image_vs_reference", "render.npz/coarse_only/f32", dict(rgb_max=e0, depth_max=z0, n_rays=256))
+    assert e0 <= 2e-5 and z0 <= 1e-4          # no resampling: continuous, tight
     prgb, pdep = _render(amd, net, g["pin_rays_o"][None], g["pin_rays_d"][None])
-    assert_image_close(oracle, prgb, pdep, g["pin_rgb"], g["pin_depth"])
+    assert_image_close(oracle, prgb, pdep, g["pin_rgb"], g["pin_depth"], name="render.npz/pinhole256/f32")
+
+
+def _hip_stages(amd, net, o, d, t_sorted_override=None):
+    """The four launches of a frame, one by one through the C ABI, returning every intermediate.  With
+    `t_sorted_override` the fine pass + compositing run on THOSE merged depths (the reference's) instead of the
+    sampler's: the attribution leg."""
+    lib, L = amd._lib.load(), amd._lib
+    n = o.shape[0]
+    st = L.stream_of(o.device)
+    t_c, u = torch.linspace(2.0, 6.0, 64).cuda(), torch.linspace(0.0, 1.0, 128).cuda()
+    raw_c = torch.empty(n, 64, 4, device="cuda")
+    L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t_c), 0, n, 64, net.packed("").data_ptr(), L.ptr(raw_c), 0, st))
+    t_sorted = torch.empty(n, 192, device="cuda")
+    L.check(lib.nerf_sample_fine(L.ptr(raw_c), L.ptr(t_c), L.ptr(u), n, L.ptr(t_sorted), None, None, 0.0, 0.0, st))
+    t_use = t_sorted if t_sorted_override is None else t_sorted_override.cuda().contiguous()
+    raw_f = torch.empty(n, 192, 4, device="cuda")
+    L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t_use), 192, n, 192, net.packed("fine").data_ptr(), L.ptr(raw_f), 0, st))
+    rgb, dep = torch.empty(n, 3, device="cuda"), torch.empty(n, device="cuda")
+    L.check(lib.nerf_composite(L.ptr(raw_f), L.ptr(t_use), 192, n, 192, 1, L.ptr(rgb), L.ptr(dep), None, st))
+    return dict(raw_coarse=raw_c, t_sorted=t_sorted, raw_fine=raw_f, rgb=rgb, depth=dep)
+
+
+@pytest.mark.parametrize("rays", ["seed", "pin"])
+@pytest.mark.parametrize("family", ["base", "sharp", "white"])
+def test_family_parity_attributed(amd, oracle, golden, synthetic_sd, family, rays):
+    """End-to-end parity on three scene families against renders of the REAL reference (render_family_*.npz), with
+    every deviation above SURVEY 8c's per-ray tolerance attributed (round-1 VERDICT "Weak 2b/2c"):
+      1. bulk: 99 % of the rays inside 1e-4 / 1e-3, PSNR bar, hard maximum pinned per family;
+      2. attribution: the reference's own merged sample depths through the HIP fine MLP + compositing put EVERY ray
+         inside 1e-4 / 1e-3 -- so whatever exceeds it end-to-end comes from sample positions, i.e. from
+      3. the sampler chain, which is checked on identical inputs: the HIP coarse densities are within 2e-5 of the
+         reference's, and the HIP sampler on the HIP densities equals the oracle's sampler on the SAME densities except
+         for a bounded number of moved samples (summation-order flips of the reference's own discontinuities).
+    All counts go to profiles/parity_r02.json."""
+    g = golden(f"render_family_{family}.npz")
+    sd = oracle.weight_family(synthetic_sd, family)
+    net = amd.Network()
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    o, d = g[f"{rays}_rays_o"].cuda(), g[f"{rays}_rays_d"].cuda()
+    ref_rgb, ref_dep, ref_t = g[f"{rays}_rgb"], g[f"{rays}_depth"], g[f"{rays}_t_sorted"]
+    n = o.shape[0]
+    with torch.no_grad():
+        rgb, dep = amd.Renderer(net).render({"rays_o": o[None], "rays_d": d[None]})
+    hip = _hip_stages(amd, net, o, d)
+    assert torch.equal(hip["rgb"], rgb) and torch.equal(hip["depth"], dep)      # the staged calls ARE the render path
+    st, over = image_stats(oracle, rgb, dep, ref_rgb, ref_dep)
+
+    # (3) sampler chain on identical inputs
+    sig_ref = g[f"{rays}_sigma_coarse_raw"]
+    sig_hip = hip["raw_coarse"][..., 3].cpu()
+    st["coarse_sigma_err_rel_to_range"] = ((sig_hip - sig_ref).abs().max() / sig_ref.abs().max()).item()
+    t_c = oracle.stratified_t().expand(n, 64)
+    t_f_same = oracle.fine_sample(torch.relu(sig_hip), t_c)                     # oracle sampler on the HIP densities
+    t_same, _ = torch.sort(torch.cat([t_c, t_f_same], 1), dim=-1)
+    dt_same = (hip["t_sorted"].cpu() - t_same).abs()
+    dt_ref = (hip["t_sorted"].cpu() - ref_t).abs()
+    for key, dt in (("sampler_same_inputs", dt_same), ("vs_reference_depths", dt_ref)):
+        st[key] = {"max_move": dt.max().item(), "samples_moved_gt_1e-5": int((dt > 1e-5).sum()),
+                   "samples_moved_gt_1e-4": int((dt > 1e-4).sum()), "samples_moved_gt_1e-3": int((dt > 1e-3).sum()),
+                   "rays_with_move_gt_1e-4": int((dt.max(1).values > 1e-4).sum())}
+    moved = dt_ref.max(1).values > 1e-5
+    st["rays_over_tolerance_without_moved_sample"] = int((over & ~moved).sum())
+
+    # (2) attribution: reference depths -> HIP fine pass + compositing
+    att = _hip_stages(amd, net, o, d, t_sorted_override=ref_t)
+    a_st, a_over = image_stats(oracle, att["rgb"], att["depth"], ref_rgb, ref_dep)
+    st["attributed_on_reference_depths"] = dict(rgb_max=a_st["rgb_max"], depth_max=a_st["depth_max"],
+                                                rays_over_tolerance=a_st["rays_over_tolerance"])
+    parity_record("family_parity_attributed", f"{family}/{rays}512/f32", st)
+    print(family, rays, st)
+
+    assert st["coarse_sigma_err_rel_to_range"] <= RAW_RTOL, st
+    # attribution, every ray, hard -- measured <= 7e-6 / 5.2e-5 on all six scenes, i.e. far inside SURVEY 8c's figures
+    assert a_st["rgb_max"] <= 2e-5 and a_st["depth_max"] <= 2e-4, st
+    assert st["rays_over_tolerance"] <= MAX_OVER_FRAC[family] * n, st
+    assert st["psnr_db"] >= {"base": 95.0, "sharp": 110.0, "white": 58.0}[family], st    # measured 107.8 / 132.3 / 65.5
+    assert st["rgb_max"] <= HARD_MAX[family][0] and st["depth_max"] <= HARD_MAX[family][1], st
+    # the sampler itself (same inputs): moves beyond a bin's rounding amplification are flips; a handful per 65 536
+    assert st["sampler_same_inputs"]["samples_moved_gt_1e-3"] <= 0.001 * n * 128, st     # measured <= 22 of 65 536
+    if family != "white":       # on the white-noise field a 1e-5 move is already visible (test_noise_floor.py)
+        assert st["rays_over_tolerance_without_moved_sample"] == 0, st
 
 
 def test_render_batched_layout_and_empty(amd, net, golden, oracle):
     g = golden("render_batched.npz")
     rgb, dep = _render(amd, net, g["rays_o"], g["rays_d"])
     assert rgb.shape == (192, 3) and dep.shape == (192,)
-    assert_image_close(oracle, rgb, dep, g["rgb"], g["depth"])
+    assert_image_close(oracle, rgb, dep, g["rgb"], g["depth"], name="render_batched.npz/f32")
     e_rgb, e_dep = _render(amd, net, torch.zeros(1, 0, 3), torch.zeros(1, 0, 3))
     assert e_rgb.shape == (0, 3) and e_dep.shape == (0,)
 
@@ -253,6 +364,13 @@ def test_render_rejects_cpu_and_bad_args(amd, net):
     assert lib.nerf_render_forward(None, None, 4, None, None, None, None, 64, 1, 0, 0, 0.25, None, 0, None, None, None) == -1
     assert lib.nerf_render_forward(None, None, 0, None, None, None, None, 128, 1, 0, 0, 0.25, None, 0, None, None, None) == 0
     assert lib.nerf_render_workspace_bytes(1000, 128, 0) == 1000 * (1024 + 768 + 3072)
+    # masked fine pass: (ray, sample) ids are int32 -> more than 2^31 / 192 rays per call is refused, not wrapped
+    # (the check precedes every launch; the dummy non-null pointers are never dereferenced)
+    big = (2 ** 31) // 192 + 1
+    need = lib.nerf_render_workspace_bytes(big, 128, 1)
+    assert lib.nerf_render_forward(8, 8, big, 8, 8, 8, 8, 128, 1, 0, 1, 0.25, 8, need, 8, 8, None) == -1
+    assert b"int32" in lib.nerf_last_error()
+    assert lib.nerf_build_flags() == 0            # product build: no timing switch compiled in
 
 
 def test_full_frame_properties(amd, net, oracle, synthetic_sd):
@@ -275,7 +393,7 @@ def test_full_frame_properties(amd, net, oracle, synthetic_sd):
     sub = idx[:512]
     with torch.no_grad():
         ref_rgb, ref_dep = oracle.render(synthetic_sd, o[sub][None], d[sub][None])
-    assert_image_close(oracle, rgb[sub], dep[sub], ref_rgb, ref_dep)
+    assert_image_close(oracle, rgb[sub], dep[sub], ref_rgb, ref_dep, name="full_frame_800x800/512_of_640000/f32")
 
 
 # =============================================================================== fp16 activation path
@@ -421,12 +539,12 @@ def test_render_masked_golden(amd, net, net16, golden, oracle):
             rgb, dep = r.render({"rays_o": g["rays_o"][None].cuda(), "rays_d": g["rays_d"][None].cuda()})
         # one more discontinuity than the plain path: a coarse weight sitting on the ESS threshold toggles
         # a fine sample in or out, so single rays may move by a whole sample's contribution
-        assert_image_close(oracle, rgb, dep, g[k_rgb], g[k_dep], max_rgb=2e-2, max_dep=1e-1)
+        assert_image_close(oracle, rgb, dep, g[k_rgb], g[k_dep], max_rgb=2e-2, max_dep=1e-1, name=f"render_masked.npz/thr{thr}/f32")
     r = amd.Renderer(net)
     r.fast_sampling = True
     with torch.no_grad():
         prgb, pdep = r.render({"rays_o": g["pin_rays_o"][None].cuda(), "rays_d": g["pin_rays_d"][None].cuda()})
-    assert_image_close(oracle, prgb, pdep, g["pin_rgb"], g["pin_depth"], max_rgb=2e-2, max_dep=1e-1)
+    assert_image_close(oracle, prgb, pdep, g["pin_rgb"], g["pin_depth"], max_rgb=2e-2, max_dep=1e-1, name="render_masked.npz/pinhole/f32")
     r16 = amd.Renderer(net16)                          # fp16 path through the same compaction
     r16.fast_sampling, r16.weights_threshold = True, 0.02
     with torch.no_grad():
@@ -494,9 +612,9 @@ def test_f32x_network_forward_fp32_tolerance(netx, net, golden):
 def test_f32x_render_golden(amd, netx, golden, oracle):
     g = golden("render.npz")
     rgb, dep = _render(amd, netx, g["rays_o"][None], g["rays_d"][None])
-    assert_image_close(oracle, rgb, dep, g["rgb_128"], g["depth_128"])
+    assert_image_close(oracle, rgb, dep, g["rgb_128"], g["depth_128"], name="render.npz/seeded256/f32x")
     prgb, pdep = _render(amd, netx, g["pin_rays_o"][None], g["pin_rays_d"][None])
-    assert_image_close(oracle, prgb, pdep, g["pin_rgb"], g["pin_depth"])
+    assert_image_close(oracle, prgb, pdep, g["pin_rgb"], g["pin_depth"], name="render.npz/pinhole256/f32x")
     rgb0, dep0 = _render(amd, netx, g["rays_o"][None], g["rays_d"][None], n_importance=0)
     assert (rgb0.cpu() - g["rgb_0"]).abs().max() <= 2e-5 and (dep0.cpu() - g["depth_0"]).abs().max() <= 1e-4
 
@@ -540,7 +658,7 @@ def test_config4_second_scene_and_pose(amd, oracle):
         ref_rgb, ref_dep = oracle.render(sd, o[None], d[None])
     rgb = torch.cat([p[0] for p in parts]); dep = torch.cat([p[1] for p in parts])
     assert torch.equal(rgb, whole[0]) and torch.equal(dep, whole[1])       # tiles == whole frame, bit for bit
-    assert_image_close(oracle, rgb, dep, ref_rgb, ref_dep)
+    assert_image_close(oracle, rgb, dep, ref_rgb, ref_dep, name="config4_second_scene/600/f32")
 
 
 def test_integration_md_ctypes_stub_runs_verbatim(amd, net):

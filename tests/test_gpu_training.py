@@ -3,6 +3,8 @@ activations and the CPU oracle under autograd."""
 import pytest
 import torch
 
+from conftest import parity_record
+
 pytestmark = pytest.mark.gpu
 
 
@@ -139,6 +141,8 @@ def test_mlp_backward_matches_autograd(amd, net, oracle, synthetic_sd, model, pr
         assert err <= 2e-4, (name, err)
     e_t = _rel(g_t, t_ref.grad)
     print(f"{prefix} [{precision}, |G|~{gscale:g}]: worst parameter-gradient error {worst:.2e}, d/dt error {e_t:.2e}")
+    parity_record("gradients", f"mlp_backward_vs_autograd/{prefix}/{precision}/G{gscale:g}",
+                  {"worst_param_rel_err": worst, "dt_rel_err": e_t})
     assert e_t <= 2e-4
 
 
@@ -161,6 +165,7 @@ def test_composite_backward_matches_autograd(amd, oracle, golden):
                                         L.stream_of(rawd.device)))
     e_raw, e_t = _rel(g_raw, raw_r.grad), _rel(g_t, t_r.grad)
     print(f"composite backward: g_raw {e_raw:.2e}, g_t {e_t:.2e}")
+    parity_record("gradients", "composite_backward_vs_autograd", {"g_raw_rel_err": e_raw, "g_t_rel_err": e_t})
     assert e_raw <= 2e-4 and e_t <= 2e-4
 
 
@@ -191,6 +196,9 @@ def test_sample_backward_matches_autograd(amd, oracle, golden):
     scale = ref[..., 3].abs().amax(dim=1).clamp_min(1e-6)
     err = (got[..., 3] - ref[..., 3]).abs().amax(dim=1) / scale
     print(f"sample backward: median ray error {err.median():.2e}, rays within 1e-3: {(err <= 1e-3).float().mean():.3f}")
+    parity_record("gradients", "sample_fine_backward/sampling.npz/256", {
+        "median_ray_err": err.median().item(), "q90_ray_err": torch.quantile(err, 0.9).item(), "max_ray_err": err.max().item(),
+        "rays_within_1e-3": int((err <= 1e-3).sum()), "rays_within_1e-4": int((err <= 1e-4).sum()), "n_rays": n})
     assert (err <= 1e-3).float().mean() >= 0.98
 
 
@@ -221,6 +229,10 @@ def test_training_step_matches_reference_autograd(amd, synthetic_sd, golden, pre
     fine = max(r[1] for r in rows if r[0].startswith("model_fine."))
     coarse = max(r[1] for r in rows if r[0].startswith("model."))
     print(f"training step: loss {loss.item():.6f}; worst relative gradient error fine {fine:.2e}, coarse {coarse:.2e} ({worst[0]})")
+    parity_record("gradients", f"training_step_vs_reference_autograd/64rays/{precision}", {
+        "loss": loss.item(), "loss_ref": g["loss"].item(), "rgb_max_err": (rgb.detach().cpu() - g["rgb"]).abs().max().item(),
+        "fine_worst_rel_err": fine, "coarse_worst_rel_err": coarse, "worst_tensor": worst[0],
+        "per_tensor_rel_err": {k: e for k, e, _ in rows}})
     # the fine model's gradients are smooth in the rounding; the coarse model's go through the inverse-CDF
     # sampler, whose index / `denom < 1e-5` flips make single rays jump (the reference's own discontinuity)
     assert fine <= 2e-3 and coarse <= 5e-2
@@ -327,3 +339,61 @@ def test_checkpoint_resume_continues_bit_identically(amd, tmp_path):
     opt_c.step()
     for pa, pc in zip(net_a.parameters(), net_c.parameters()):
         assert torch.equal(pa.detach(), pc.detach())
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32x"])
+@pytest.mark.parametrize("model,prefix", [("fine", "model_fine"), ("", "model")])
+def test_network_forward_is_differentiable(amd, oracle, synthetic_sd, model, prefix, precision):
+    """Network.forward itself under autograd (reference: network.py:199-258 is an ordinary differentiable module):
+    loss = sum(raw * G) -> gradients of the 24 tensors of the selected sub-model AND of `inputs`, against
+    oracle.network_forward under torch autograd.  viewdirs are deliberately NOT unit length: Network.forward uses them
+    as given (only the renderer normalises, volume_renderer.py:314).  Also the masked (ESS/ERT) call."""
+    gen = torch.Generator().manual_seed(17)
+    n, S = 9, 7                                               # 63 points: ragged tile
+    pts = (torch.rand(n, S, 3, generator=gen) * 2 - 1) * 2.5
+    vd = torch.randn(n, 3, generator=gen) * 0.7
+    G = torch.randn(n, S, 4, generator=gen)
+    mask = torch.rand(n, S, generator=gen) > 0.35
+    net = amd.Network()
+    net.load_state_dict(synthetic_sd, strict=True)
+    net = net.cuda().train()
+    net.precision = precision
+    sub = net.model_fine if model == "fine" else net.model
+    other = net.model if model == "fine" else net.model_fine
+    names = [f"{prefix}.{k}" for k in oracle.SUBMODEL_KEYS]
+    for tag, msk in (("unmasked", None), ("masked", mask)):
+        # ---- oracle
+        sd = {k: v.clone().requires_grad_(k.startswith(prefix + ".")) for k, v in synthetic_sd.items()}
+        p_ref = pts.clone().requires_grad_(True)
+        raw_ref = oracle.network_forward(sd, p_ref, vd, model)
+        if msk is not None:
+            raw_ref = raw_ref * msk[..., None]                # network.py:238-253: zeros where masked out
+        (raw_ref * G).sum().backward()
+        # ---- HIP through nn.Module.__call__
+        net.zero_grad(set_to_none=True)
+        p_hip = pts.cuda().requires_grad_(True)
+        raw = net(p_hip, vd.cuda(), None if msk is None else msk.cuda(), model)
+        assert raw.requires_grad and raw.shape == (n, S, 4)
+        (raw * G.cuda()).sum().backward()
+        assert _rel(raw.detach(), raw_ref.detach()) <= 2e-5
+        worst = 0.0
+        for name, p in zip(names, sub.ordered_params()):
+            err = _rel(p.grad, sd[name].grad)
+            worst = max(worst, err)
+            assert err <= 2e-4, (tag, name, err)
+        e_x = _rel(p_hip.grad, p_ref.grad)
+        assert e_x <= 2e-4, (tag, e_x)
+        assert all(p.grad is None for p in other.parameters())               # the other sub-model is not touched
+        if msk is not None:
+            assert torch.all(p_hip.grad.cpu()[~msk] == 0) and torch.all(raw.detach().cpu()[~msk] == 0)
+        parity_record("gradients", f"network_forward_autograd/{prefix}/{precision}/{tag}",
+                      {"worst_param_rel_err": worst, "d_inputs_rel_err": e_x})
+    # eval() + no_grad stays the inference kernel; grad w.r.t. inputs alone works on an eval() network too
+    net.eval()
+    with torch.no_grad():
+        assert not net(pts.cuda(), vd.cuda(), None, model).requires_grad
+    p_hip = pts.cuda().requires_grad_(True)
+    net(p_hip, vd.cuda(), None, model).sum().backward()
+    assert p_hip.grad is not None and torch.isfinite(p_hip.grad).all()
+    with pytest.raises(NotImplementedError):
+        net(p_hip, vd.cuda().requires_grad_(True), None, model)

@@ -138,3 +138,28 @@ def test_ess_ert_masked_path(oracle, golden, synthetic_sd):
                                    weights_threshold=0.02)
     assert (rgb - g["rgb"]).abs().max() <= 1e-6 and (dep - g["depth"]).abs().max() <= 1e-5
     assert (rgb2 - g["rgb_thr002"]).abs().max() <= 1e-6 and (dep2 - g["depth_thr002"]).abs().max() <= 1e-5
+
+
+@pytest.mark.parametrize("family", ["base", "sharp", "white"])
+def test_weight_family_renders(oracle, golden, synthetic_sd, family):
+    """Round 2: parity scenes beyond the benign band-limited field.  The family state_dicts are exact elementwise
+    transforms of the committed checkpoint (bit-reproducible anywhere); the REAL reference rendered them in
+    oracle/gen_golden.py::family_fixtures.  Oracle image and merged sample depths: bit-exact."""
+    g = golden(f"render_family_{family}.npz")
+    sd = oracle.weight_family(synthetic_sd, family)
+    for tag in ("seed", "pin"):
+        o, d = g[f"{tag}_rays_o"], g[f"{tag}_rays_d"]
+        with torch.no_grad():
+            rgb, dep, parts = oracle.render(sd, o[None], d[None], return_parts=True)
+        assert torch.equal(parts["raw_coarse"][..., 3], g[f"{tag}_sigma_coarse_raw"])
+        assert torch.equal(parts["t_sorted"], g[f"{tag}_t_sorted"])
+        assert torch.equal(rgb, g[f"{tag}_rgb"]) and torch.equal(dep, g[f"{tag}_depth"])
+    o, d = oracle.seeded_rays(512, 31)
+    assert torch.equal(o, g["seed_rays_o"]) and torch.equal(d, g["seed_rays_d"])
+    # what makes each family what it says: occupancy / sharpness of the coarse density along the fixture rays
+    sig = torch.cat([g["seed_sigma_coarse_raw"], g["pin_sigma_coarse_raw"]])
+    occ, std = (sig > 0).float().mean().item(), sig.std().item()
+    want = {"base": (0.15, 0.45, 4, 16), "sharp": (0.01, 0.10, 40, 90), "white": (0.15, 0.45, 4, 16)}[family]
+    assert want[0] <= occ <= want[1] and want[2] <= std <= want[3], (family, occ, std)
+    assert torch.equal(oracle.weight_family(synthetic_sd, "base")["model.alpha_linear.bias"],
+                       synthetic_sd["model.alpha_linear.bias"])

@@ -18,7 +18,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 CSRC = os.path.join(REPO, "nerf_replication_amd", "csrc")
 VDIR = os.path.join(CSRC, "variants")
-FLAGS = "-O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -shared -fPIC"
+FLAGS = "-O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -shared -fPIC -DNERF_TIMING_BUILD"
 
 
 def build(name, extra):

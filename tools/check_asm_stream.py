@@ -5,7 +5,8 @@ inference instances) and nerf_wgrad256_f32_asm_kernel.
 The asm `global_load_dwordx4` loads are asynchronous behind the compiler's back: between a load and the asm
 `s_waitcnt vmcnt(N)` that covers it, NO instruction may read or write the destination registers (the compiler could
 spill, copy or reuse them -- it believes the asm's outputs are ready immediately).  This script compiles the kernels to
-ISA and verifies exactly that for every asm load; it is run by tests/test_abi_symbols.py.
+ISA and verifies exactly that for every asm load; csrc/Makefile runs it on every build of the library (with the
+build's own flags; a hazard fails the build) and tests/test_abi_symbols.py runs it with a negative self-test.
 
     python tools/check_asm_stream.py        # exit status 0 = no hazard
 """
@@ -18,9 +19,12 @@ import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "nerf_replication_amd", "csrc", "nerf_kernels.hip")
-FLAGS = "-O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -S --cuda-device-only"
+# code-generation flags: the Makefile passes ITS OWN ($(CXXFLAGS)) through --flags, so the ISA checked here is the ISA
+# of the library being built; the default below mirrors csrc/Makefile for stand-alone runs
+FLAGS = "-O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950"
+HIPCC = "/opt/rocm/bin/hipcc"
 KERNELS = ["_Z19nerf_mlp_f32_kernelILb1ELb0EEv7MlpArgs", "_Z19nerf_mlp_f32_kernelILb0ELb0EEv7MlpArgs",
-           "_Z19nerf_mlp_f32_kernelILb1ELb1EEv7MlpArgs",
+           "_Z19nerf_mlp_f32_kernelILb1ELb1EEv7MlpArgs", "_Z19nerf_mlp_f32_kernelILb0ELb1EEv7MlpArgs",
            "_Z28nerf_wgrad256_f32_asm_kernel10WgradBatch"]
 
 
@@ -85,10 +89,16 @@ def check(lines, name):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--flags", default=FLAGS, help="code-generation flags of the build being checked (csrc/Makefile: $(CXXFLAGS))")
+    ap.add_argument("--hipcc", default=HIPCC)
+    args = ap.parse_args()
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
-        extra = os.environ.get("NERF_CHECK_EXTRA_FLAGS", "")     # e.g. -DNERF_F32_ASM_OVERRUN=1: must report hazards
-        subprocess.run(f"/opt/rocm/bin/hipcc {FLAGS} {extra} -o {out} {SRC}", shell=True, check=True, stderr=subprocess.DEVNULL)
+        extra = os.environ.get("NERF_CHECK_EXTRA_FLAGS", "")     # e.g. -DNERF_F32_ASM_OVERRUN=1 -DNERF_TIMING_BUILD: must report hazards
+        subprocess.run(f"{args.hipcc} {args.flags} -S --cuda-device-only {extra} -o {out} {SRC}", shell=True, check=True,
+                       stderr=subprocess.DEVNULL)
         lines = open(out).read().split("\n")
     bad = 0
     for k in KERNELS:
