@@ -539,12 +539,12 @@ def test_render_masked_golden(amd, net, net16, golden, oracle):
             rgb, dep = r.render({"rays_o": g["rays_o"][None].cuda(), "rays_d": g["rays_d"][None].cuda()})
         # one more discontinuity than the plain path: a coarse weight sitting on the ESS threshold toggles
         # a fine sample in or out, so single rays may move by a whole sample's contribution
-        assert_image_close(oracle, rgb, dep, g[k_rgb], g[k_dep], max_rgb=2e-2, max_dep=1e-1, name=f"render_masked.npz/thr{thr}/f32")
+        assert_image_close(oracle, rgb, dep, g[k_rgb], g[k_dep], max_rgb=5e-4, max_dep=2e-3, name=f"render_masked.npz/thr{thr}/f32")       # measured 1.4e-4 / 5.9e-4
     r = amd.Renderer(net)
     r.fast_sampling = True
     with torch.no_grad():
         prgb, pdep = r.render({"rays_o": g["pin_rays_o"][None].cuda(), "rays_d": g["pin_rays_d"][None].cuda()})
-    assert_image_close(oracle, prgb, pdep, g["pin_rgb"], g["pin_depth"], max_rgb=2e-2, max_dep=1e-1, name="render_masked.npz/pinhole/f32")
+    assert_image_close(oracle, prgb, pdep, g["pin_rgb"], g["pin_depth"], max_rgb=1.6e-2, max_dep=7e-2, name="render_masked.npz/pinhole/f32")   # measured 5.2e-3 / 2.4e-2 (one ray toggles a fine sample)
     r16 = amd.Renderer(net16)                          # fp16 path through the same compaction
     r16.fast_sampling, r16.weights_threshold = True, 0.02
     with torch.no_grad():

@@ -138,12 +138,12 @@ def test_mlp_backward_matches_autograd(amd, net, oracle, synthetic_sd, model, pr
         ref = sd[name].grad
         err = _rel(got, ref)
         worst = max(worst, err)
-        assert err <= 2e-4, (name, err)
+        assert err <= 1e-5, (name, err)          # measured <= 1.2e-6 (profiles/parity_r02.json)
     e_t = _rel(g_t, t_ref.grad)
     print(f"{prefix} [{precision}, |G|~{gscale:g}]: worst parameter-gradient error {worst:.2e}, d/dt error {e_t:.2e}")
     parity_record("gradients", f"mlp_backward_vs_autograd/{prefix}/{precision}/G{gscale:g}",
                   {"worst_param_rel_err": worst, "dt_rel_err": e_t})
-    assert e_t <= 2e-4
+    assert e_t <= 1e-5
 
 
 def test_composite_backward_matches_autograd(amd, oracle, golden):
@@ -166,7 +166,7 @@ def test_composite_backward_matches_autograd(amd, oracle, golden):
     e_raw, e_t = _rel(g_raw, raw_r.grad), _rel(g_t, t_r.grad)
     print(f"composite backward: g_raw {e_raw:.2e}, g_t {e_t:.2e}")
     parity_record("gradients", "composite_backward_vs_autograd", {"g_raw_rel_err": e_raw, "g_t_rel_err": e_t})
-    assert e_raw <= 2e-4 and e_t <= 2e-4
+    assert e_raw <= 1e-5 and e_t <= 1e-5          # measured 1.1e-6 / 2.0e-6
 
 
 def test_sample_backward_matches_autograd(amd, oracle, golden):
@@ -199,7 +199,8 @@ def test_sample_backward_matches_autograd(amd, oracle, golden):
     parity_record("gradients", "sample_fine_backward/sampling.npz/256", {
         "median_ray_err": err.median().item(), "q90_ray_err": torch.quantile(err, 0.9).item(), "max_ray_err": err.max().item(),
         "rays_within_1e-3": int((err <= 1e-3).sum()), "rays_within_1e-4": int((err <= 1e-4).sum()), "n_rays": n})
-    assert (err <= 1e-3).float().mean() >= 0.98
+    # measured: 254 of 256 rays within 1e-3, 243 within 1e-4, median 5.6e-6
+    assert (err <= 1e-3).float().mean() >= 0.98 and (err <= 1e-4).float().mean() >= 0.90 and err.median() <= 5e-5
 
 
 @pytest.mark.parametrize("precision", ["f32", "f32x"])
@@ -235,7 +236,8 @@ def test_training_step_matches_reference_autograd(amd, synthetic_sd, golden, pre
         "per_tensor_rel_err": {k: e for k, e, _ in rows}})
     # the fine model's gradients are smooth in the rounding; the coarse model's go through the inverse-CDF
     # sampler, whose index / `denom < 1e-5` flips make single rays jump (the reference's own discontinuity)
-    assert fine <= 2e-3 and coarse <= 5e-2
+    # measured (profiles/parity_r02.json): fine 1.2e-4 (f32) / 1.6e-4 (f32x), coarse 5.1e-3 / 8.6e-3 -> ~3x
+    assert fine <= 5e-4 and coarse <= 2.5e-2
     # coarse colour layers receive exactly zero gradient: the coarse RGB is never composited
     for k in ("model.rgb_linear.weight", "model.views_linears.0.weight", "model.feature_linear.weight"):
         assert torch.all(dict(net.named_parameters())[k].grad == 0), k
@@ -380,9 +382,9 @@ def test_network_forward_is_differentiable(amd, oracle, synthetic_sd, model, pre
         for name, p in zip(names, sub.ordered_params()):
             err = _rel(p.grad, sd[name].grad)
             worst = max(worst, err)
-            assert err <= 2e-4, (tag, name, err)
+            assert err <= 1e-5, (tag, name, err)         # measured <= 1.3e-6
         e_x = _rel(p_hip.grad, p_ref.grad)
-        assert e_x <= 2e-4, (tag, e_x)
+        assert e_x <= 1e-5, (tag, e_x)
         assert all(p.grad is None for p in other.parameters())               # the other sub-model is not touched
         if msk is not None:
             assert torch.all(p_hip.grad.cpu()[~msk] == 0) and torch.all(raw.detach().cpu()[~msk] == 0)
