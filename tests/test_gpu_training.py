@@ -43,7 +43,8 @@ def test_forward_save_matches_reference_activations(amd, net, golden, precision)
         L.check(lib.nerf_mlp_forward_rays_save(L.ptr(o), L.ptr(d), L.ptr(t), 1, P, 1, net.packed(model).data_ptr(),
                                                L.ptr(raw), L.ptr(save), prec, L.stream_of(o.device)))
         sv = save.cpu()
-        assert torch.isfinite(sv).all()
+        rows = P * (96 + 2304 + 128)                   # (P is a multiple of 32: no padding rows)
+        assert torch.isfinite(sv[:rows]).all()
         pe, dpe = sv[:P * 64].view(P, 64), sv[P * 64:P * 96].view(P, 32)
         assert (pe[:, :63] - g["emb"][:, :63]).abs().max() <= 5e-7 and torch.all(pe[:, 63] == 0)
         # rays_d / ||rays_d|| in-kernel may differ from the fixture's direction by an ulp, x8 at octave 3
@@ -52,9 +53,25 @@ def test_forward_save_matches_reference_activations(amd, net, golden, precision)
             h = sv[P * (96 + 256 * l):P * (96 + 256 * (l + 1))].view(P, 256)
             assert _rel(h, g[f"{tag}_h{l}"]) <= 2e-5, l
         f = sv[P * (96 + 2048):P * (96 + 2304)].view(P, 256)
-        hv = sv[P * (96 + 2304):].view(P, 128)
+        hv = sv[P * (96 + 2304):rows].view(P, 128)
         assert _rel(f, g[f"{tag}_feature"]) <= 2e-5 and _rel(hv, g[f"{tag}_views"]) <= 2e-5
         assert _rel(raw[:, 0], g[f"{tag}_out"]) <= 2e-5
+        if precision == "f32":
+            # behind the rows (fp32 SAVE forward only): ReLU sign bits in accumulator layout, one 1-KiB block per
+            # 32-point tile and masked tensor (h0..h7, views), and the xyz encoding in B-operand layout
+            bits = sv[rows:rows + (P // 32) * 9 * 256].view(torch.int32).view(P // 32, 9, 64, 4)
+            lane = torch.arange(64)
+            pt, hh = lane & 31, lane >> 5
+            for which, key, ntile in [(l, f"{tag}_h{l}", 8) for l in range(8)] + [(8, f"{tag}_views", 4)]:
+                act = g[key].view(P // 32, 32, -1)
+                for t in range(ntile):
+                    for r in range(16):
+                        feat = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh                       # act_feat(t, r, h)
+                        want = act[:, pt, feat] > 0                                         # [tiles, 64]
+                        got = (bits[:, which, :, t >> 1] >> (16 * (t & 1) + r)) & 1
+                        # (an activation within rounding of 0 may differ in sign between the GPU and the fixture)
+                        near0 = act[:, pt, feat].abs() < 1e-6
+                        assert torch.all((got.bool() == want) | near0), (tag, which, t, r)
     net.precision = "f32"
 
 
