@@ -64,14 +64,14 @@ def test_forward_save_matches_reference_activations(amd, net, golden, precision)
             pt, hh = lane & 31, lane >> 5
             for which, key, ntile in [(l, f"{tag}_h{l}", 8) for l in range(8)] + [(8, f"{tag}_views", 4)]:
                 act = g[key].view(P // 32, 32, -1)
-                for t in range(ntile):
+                for ti in range(ntile):
                     for r in range(16):
-                        feat = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh                       # act_feat(t, r, h)
+                        feat = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * hh                      # act_feat(t, r, h)
                         want = act[:, pt, feat] > 0                                         # [tiles, 64]
-                        got = (bits[:, which, :, t >> 1] >> (16 * (t & 1) + r)) & 1
+                        got = (bits[:, which, :, ti >> 1] >> (16 * (ti & 1) + r)) & 1
                         # (an activation within rounding of 0 may differ in sign between the GPU and the fixture)
                         near0 = act[:, pt, feat].abs() < 1e-6
-                        assert torch.all((got.bool() == want) | near0), (tag, which, t, r)
+                        assert torch.all((got.bool() == want) | near0), (tag, which, ti, r)
     net.precision = "f32"
 
 
