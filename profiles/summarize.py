@@ -43,9 +43,68 @@ if out:          # (trace-only collections have no counter passes: no empty file
               note = f"KiB units -> {m * 1024 / 1e6:.1f} MB/dispatch"
           w.writerow([k, g, c, len(v), f"{m:.0f}", note])
 
+# ---- per-kernel attribution of the SQ counters (round-2 VERDICT item 5): where the non-MFMA cycles go
+sq = {}
+for d in sorted(glob.glob(os.path.join(src, "pmc_sq"))):
+    for r in csv.DictReader(open(newest(os.path.join(d, "*", "*_counter_collection.csv")))):
+        if "nerf_" not in r["Kernel_Name"]:
+            continue
+        k = r["Kernel_Name"].split("(")[0][-48:]
+        e = sq.setdefault(k, {"dispatches": set()})
+        e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        e["dispatches"].add(r["Dispatch_Id"])
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            e["_ns"] = e.get("_ns", 0.0) + float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+if sq:
+    with open(os.path.join(here, f"{tag}_sq_summary.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "dispatches", "clock_ghz", "mfma_busy_frac_of_simd_cycles", "wave_wait_any_frac", "wave_wait_inst_any_frac",
+                    "valu_inst_per_wave_cycle", "lds_bank_conflict_cycles_per_busy_cycle",
+                    "note: fractions of SQ_WAVE_CYCLES except mfma_busy (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128 SIMD-slots))"])
+        for k, e in sorted(sq.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0)):
+            g = e.get("GRBM_GUI_ACTIVE", 0.0)
+            wc = e.get("SQ_WAVE_CYCLES", 0.0)
+            if g <= 0 or wc <= 0:
+                continue
+            w.writerow([k, len(e["dispatches"]), f"{g / e['_ns'] / 8.0:.3f}" if e.get("_ns") else "",
+                        f"{e.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (g * 128.0):.4f}",
+                        f"{e.get('SQ_WAIT_ANY', 0.0) / wc:.4f}", f"{e.get('SQ_WAIT_INST_ANY', 0.0) / wc:.4f}",
+                        f"{e.get('SQ_ACTIVE_INST_VALU', 0.0) / wc:.4f}",
+                        f"{e.get('SQ_LDS_BANK_CONFLICT', 0.0) / max(1.0, e.get('SQ_BUSY_CYCLES', 0.0)):.5f}", ""])
+    print("wrote", f"{tag}_sq_summary.csv")
+
+# ---- training step: HBM bytes per step (all kernels of a step), for bench.py's training.roofline.traffic
+if "train" in tag:
+    import json
+    tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+    per_kernel = {}
+    steps_seen = 0
+    for d in sorted(glob.glob(os.path.join(src, "pmc_fetch")) + glob.glob(os.path.join(src, "pmc_write"))):
+        for r in csv.DictReader(open(newest(os.path.join(d, "*", "*_counter_collection.csv")))):
+            if "nerf_" not in r["Kernel_Name"] or r["Counter_Name"] not in tot:
+                continue
+            v = float(r["Counter_Value"]) * 1024 * (2 if r["Counter_Name"] == "FETCH_SIZE" else 1)
+            tot[r["Counter_Name"]] += v
+            pk = per_kernel.setdefault(r["Kernel_Name"].split("(")[0][-48:], {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
+            pk[r["Counter_Name"]] += v
+            if "nerf_adam_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
+                steps_seen += 1                                   # one Adam launch per step
+    steps_seen = max(1, steps_seen)
+    prec_t = tag.split("train_", 1)[1]
+    out_t = {"workload": "BASELINE configs[2]: 4096 rays/iter, fwd(save)+bwd+Adam, 1 GPU", "steps_profiled": steps_seen,
+             "fetch_bytes_per_step": tot["FETCH_SIZE"] / steps_seen, "write_bytes_per_step": tot["WRITE_SIZE"] / steps_seen,
+             "traffic_bytes_per_step": (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / steps_seen,
+             "per_kernel_bytes_per_step": {k: {"fetch": v["FETCH_SIZE"] / steps_seen, "write": v["WRITE_SIZE"] / steps_seen}
+                                           for k, v in sorted(per_kernel.items())},
+             "source": f"profiles/{tag}_pmc.csv (profiles/collect.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of "
+                       "`bench.py --mode train`; FETCH_SIZE KiB x2 gfx950 wide-read correction, WRITE_SIZE KiB exact; summed over "
+                       "every kernel of a step)"}
+    json.dump(out_t, open(os.path.join(here, f"traffic_train_{prec_t}.json"), "w"), indent=1)
+    print("wrote", f"traffic_train_{prec_t}.json", round(out_t["traffic_bytes_per_step"] / 1e9, 2), "GB/step")
+
 # traffic_<prec>.json: what bench.py reports as roofline.traffic (per launch of the dominant kernel, averaged over the
 # coarse and fine launches exactly as `rocprofv3 --stats` averages their durations)
-prec = tag.split("_", 1)[1] if tag.startswith("r01_") or tag[:1] == "r" else None
+prec = tag.split("_", 1)[1] if (tag[:1] == "r" and "train" not in tag) else None
 kname = {"f32": "nerf_mlp_f32_kernel", "f16": "nerf_mlp_f16_kernel", "f32x": "nerf_mlp_f32x_kernel"}.get(prec)
 if kname:
     import json
