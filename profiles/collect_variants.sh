@@ -1,0 +1,14 @@
+#!/bin/bash
+# What bounds the fp16 kernel: busy x clock of timing-only build variants (tools/ab_bench.py builds them with
+# -DNERF_TIMING_BUILD; they compute wrong results and are never loaded by the product).  One rocprofv3 process per
+# variant, so every nerf_mlp_f16_kernel dispatch in its output belongs to that variant.
+#   bash profiles/collect_variants.sh   -> gpurun_out/var_<name>/{trace,pmc}
+#   python profiles/summarize_variants.py gpurun_out r02_f16_variants
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
+for V in ${VARIANTS:-base noadv noepi noboth}; do
+  D=gpurun_out/var_$V; mkdir -p $D
+  AB_ROUNDS=5 rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 tools/ab_bench.py f16 $V: > $D/trace.log 2>&1
+  AB_ROUNDS=3 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $D/pmc -- python3 tools/ab_bench.py f16 $V: > $D/pmc.log 2>&1
+  tail -1 $D/trace.log
+done

@@ -685,3 +685,37 @@ def test_integration_md_ctypes_stub_runs_verbatim(amd, net):
     with torch.no_grad():
         rgb2, dep2 = amd.Renderer(net).render({"rays_o": o[None], "rays_d": d[None]})
     assert torch.equal(rgb, rgb2) and torch.equal(dep, dep2)
+
+
+def test_bench_two_rank_path_on_one_gpu():
+    """bench.py's N>1 branch, rehearsed on the one GPU of this box (round-1 VERDICT "Weak 7c"): two ranks launched exactly
+    as the driver does (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`), both on cuda:0
+    (NERF_BENCH_SHARE_GPU=1) with gloo as the collective backend (RCCL refuses two ranks on one device).  Every rank
+    generates and renders only its own tile; the all_gather, the max-over-ranks timing, the per-rank compute times and
+    the training / config5 blocks with their collectives all run.  The JSON line must be self-consistent."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, NERF_BENCH_SHARE_GPU="1", NERF_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--res", "800"]
+    res = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]                    # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["dist_backend"] == "gloo" and out["steps"] == 1
+    assert out["scaling"] == "strong" and out["config"]["rays_per_step"] == 640000 and out["dtype"] == "f32"
+    assert abs(out["value"] - 640000 / (out["ms_per_step"] * 1e-3)) <= 1e-3 * out["value"]
+    assert len(out["per_rank_compute_ms"]) == 2 and all(0 < t <= out["ms_per_step"] * 1.05 for t in out["per_rank_compute_ms"])
+    assert "cpu_baseline" not in out                               # N=1 only
+    # (two ranks SHARE one GPU here, so nothing is said about speed; the blocks must exist and be error-free)
+    assert "error" not in out["training"] and out["training"]["n_gpus"] == 2
+    assert out["training"]["f32"]["rays_per_iter_per_gpu"] == 4096 and out["training"]["f32x"]["ms_per_step"] > 0
+    assert "error" not in out["config5"] and out["config5"]["finite"] and out["config5"]["n_gpus"] == 2
