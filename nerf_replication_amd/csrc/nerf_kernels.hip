@@ -1032,7 +1032,11 @@ int32_t nerf_wgrad(const float* dz, int64_t ldz, int32_t zc0, int32_t n_out, con
   long long blocks = (pairs + 255) / 256;            // >= 256 point pairs per workgroup
   if (blocks > num_cus()) blocks = num_cus();
   if (blocks < 1) blocks = 1;
-  const dim3 grid((unsigned)blocks), blk(256);
+  // the small-layer (vector-load) kernels may run NERF_WGVEC_WAVES workgroups per CU
+  long long vblocks = (pairs + 255) / 256;
+  if (vblocks > (long long)num_cus() * NERF_WGVEC_WAVES) vblocks = (long long)num_cus() * NERF_WGVEC_WAVES;
+  if (vblocks < 1) vblocks = 1;
+  const dim3 grid((unsigned)blocks), vgrid((unsigned)vblocks), blk(256);
   hipStream_t st = (hipStream_t)stream;
   const bool aligned = ldz % 4 == 0 && ldh % 4 == 0 && zc0 % 4 == 0 && hc0 % 4 == 0 &&
                        (uintptr_t)dz % 16 == 0 && (uintptr_t)hin % 16 == 0;
@@ -1049,15 +1053,15 @@ int32_t nerf_wgrad(const float* dz, int64_t ldz, int32_t zc0, int32_t n_out, con
   // small layers on the vector-load kernel: (floats per lane, wave split) chosen so that 32*AV*osplit covers n_out
   // and 32*BV*isplit covers n_in; operands must be aligned to their vector width
   else if (n_out == 256 && n_in <= 64 && aligned) {                                      // PE -> 256 (layers 0 and 5)
-    a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<4, 1>), grid, blk, 0, st, a);
+    a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<4, 1>), vgrid, blk, 0, st, a);
   } else if (n_out == 128 && n_in == 256 && aligned) {                                   // views_linears.0, feature part
-    a.osplit = 1; a.isplit = 4; hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<4, 2>), grid, blk, 0, st, a);
+    a.osplit = 1; a.isplit = 4; hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<4, 2>), vgrid, blk, 0, st, a);
   } else if (n_out == 128 && n_in <= 32) {                                               // views_linears.0, direction part
-    a.osplit = 4; a.isplit = 1; hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<1, 1>), grid, blk, 0, st, a);
+    a.osplit = 4; a.isplit = 1; hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<1, 1>), vgrid, blk, 0, st, a);
   } else if (n_out <= 32 && n_in == 256 && ldh % 2 == 0 && hc0 % 2 == 0 && (uintptr_t)hin % 8 == 0) {   // alpha_linear
-    a.osplit = 1; a.isplit = 4; hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<1, 2>), grid, blk, 0, st, a);
+    a.osplit = 1; a.isplit = 4; hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<1, 2>), vgrid, blk, 0, st, a);
   } else if (n_out <= 32 && n_in <= 128) {                                               // rgb_linear
-    a.osplit = 1; a.isplit = 4; hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<1, 1>), grid, blk, 0, st, a);
+    a.osplit = 1; a.isplit = 4; hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<1, 1>), vgrid, blk, 0, st, a);
   }
   else if (to > 4 && ti > 4) { a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<4, 4>), grid, blk, 0, st, a); }
   else if (to > 4)           { a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<4, 1>), grid, blk, 0, st, a); }

@@ -15,6 +15,14 @@ src, tag = sys.argv[1], sys.argv[2]
 newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)      # a directory may hold older runs too
 here = os.path.dirname(os.path.abspath(__file__))
 
+
+def kname_of(full):
+    """nerf_xxx_kernel<template args> out of a demangled name (anonymous-namespace prefixes and argument lists dropped)."""
+    import re
+    m = re.search(r"nerf_\w+(<[^(]*>)?", full)
+    return m.group(0) if m else full[:48]
+
+
 rows = list(csv.DictReader(open(newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv")))))
 with open(os.path.join(here, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     w = csv.writer(f)
@@ -28,7 +36,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     for r in csv.DictReader(open(newest(os.path.join(d, "*", "*_counter_collection.csv")))):
         if "nerf_" not in r["Kernel_Name"]:
             continue
-        key = (r["Kernel_Name"].split("(")[0][-40:], r["Grid_Size"], r["Counter_Name"])
+        key = (kname_of(r["Kernel_Name"]), r["Grid_Size"], r["Counter_Name"])
         out.setdefault(key, []).append(float(r["Counter_Value"]))
 if out:          # (trace-only collections have no counter passes: no empty file)
   with open(os.path.join(here, f"{tag}_pmc.csv"), "w", newline="") as f:
@@ -49,7 +57,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_sq"))):
     for r in csv.DictReader(open(newest(os.path.join(d, "*", "*_counter_collection.csv")))):
         if "nerf_" not in r["Kernel_Name"]:
             continue
-        k = r["Kernel_Name"].split("(")[0][-48:]
+        k = kname_of(r["Kernel_Name"])
         e = sq.setdefault(k, {"dispatches": set()})
         e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         e["dispatches"].add(r["Dispatch_Id"])
@@ -85,7 +93,7 @@ if "train" in tag:
                 continue
             v = float(r["Counter_Value"]) * 1024 * (2 if r["Counter_Name"] == "FETCH_SIZE" else 1)
             tot[r["Counter_Name"]] += v
-            pk = per_kernel.setdefault(r["Kernel_Name"].split("(")[0][-48:], {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
+            pk = per_kernel.setdefault(kname_of(r["Kernel_Name"]), {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
             pk[r["Counter_Name"]] += v
             if "nerf_adam_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
                 steps_seen += 1                                   # one Adam launch per step
