@@ -101,7 +101,11 @@ int32_t nerf_mlp_forward_rays_save(const float* rays_o, const float* rays_d, con
  * nerf_train_grad_floats(P) floats (receives every layer's pre-activation gradient).  Adds the 24
  * parameter gradients (state_dict order, nn.Linear layouts; the caller zeroes them) and, if `g_t` [P]
  * is given, writes d loss / d t through the points (x = o + d t, positional encoding included) -- the
- * path by which the coarse network is trained. */
+ * path by which the coarse network is trained.
+ * NERF_PREC_F32 needs a `save` written by the NERF_PREC_F32 SAVE forward: its ReLU masks come from the sign-bit blocks
+ * that forward appends behind the activation rows (nerf_train_save_floats covers them); NERF_PREC_F32X reads the rows
+ * themselves and accepts a `save` of either forward.  Both `save` and `gsave` regions hold their rows padded to a
+ * multiple of 32 points (offsets are derived from the padded count, see csrc/nerf_mlp_f32.hip.inc TrainSave). */
 int64_t nerf_train_grad_floats(int64_t n_points);
 int64_t nerf_packed_bwd_bytes(int32_t precision);
 int32_t nerf_pack_model_bwd(const float* const params[24], void* packed_bwd, int32_t precision, void* stream);
