@@ -302,6 +302,13 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        # communicator setup (RCCL builds its rings lazily on the first collective of each kind): done here, outside any
+        # step, so that even `--warmup 0` times the frame and not the library's initialisation
+        _w = torch.zeros(4, device=dev)
+        dist.all_reduce(_w)
+        _g = torch.empty(4 * world, device=dev)
+        dist.all_gather_into_tensor(_g, _w)
+        torch.cuda.synchronize()
 
     import nerf_replication_amd as pkg
     from nerf_replication_amd.dist import render_shard, shard_bounds
