@@ -26,6 +26,21 @@ def build(name, extra):
     out = os.path.join(VDIR, f"lib_{name}.so")
     cmd = f"/opt/rocm/bin/hipcc {FLAGS} {extra} -o {out} {os.path.join(CSRC, 'nerf_kernels.hip')}"
     subprocess.run(cmd, shell=True, check=True)
+    with open(out + ".flags", "w") as f:          # what this binary was built with: a stale or flag-less rebuild cannot pose as it
+        f.write(extra.strip())
+    return out
+
+
+def ensure(name, extra, force=False):
+    """Path of variant `name`, (re)built when missing, when `extra` differs from what the existing binary was built with, or
+    on `force`.  A spec without flags ("name:") reuses an existing binary but never BUILDS one unless the name is base/new."""
+    out = os.path.join(VDIR, f"lib_{name}.so")
+    have = open(out + ".flags").read() if os.path.exists(out) and os.path.exists(out + ".flags") else None
+    extra = extra.strip()
+    if have is None and not extra and name not in ("base", "new"):
+        raise SystemExit(f"variant {name!r}: no binary and no flags given -- refusing to build a flag-less look-alike")
+    if force or have is None or (extra and extra != have):
+        build(name, extra)
     return out
 
 
@@ -35,10 +50,7 @@ def main():
     build_only = os.environ.get("AB_BUILD_ONLY") == "1"
     libs = {}
     for name, extra in specs:
-        path = os.path.join(VDIR, f"lib_{name}.so")
-        if build_only or not os.path.exists(path):
-            build(name, extra)
-        libs[name] = path
+        libs[name] = ensure(name, extra, force=build_only)
     if build_only:
         print("built", list(libs))
         return

@@ -23,10 +23,7 @@ def main():
     specs = [s.split(":", 1) for s in sys.argv[2:]]
     libs = {}
     for name, extra in specs:
-        path = os.path.join(ab_bench.VDIR, f"lib_{name}.so")
-        if os.environ.get("AB_BUILD_ONLY") == "1" or not os.path.exists(path):
-            ab_bench.build(name, extra)
-        libs[name] = path
+        libs[name] = ab_bench.ensure(name, extra, force=os.environ.get("AB_BUILD_ONLY") == "1")
     if os.environ.get("AB_BUILD_ONLY") == "1":
         print("built", list(libs))
         return
