@@ -114,6 +114,21 @@ int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float*
                           const float* save, float* gsave, float* g_t, float* const grads[24], int32_t precision,
                           void* stream);
 
+/* Density-only twins for the COARSE pass of a training step.  In the reference's step only the coarse sigma is ever used
+ * (it places the fine samples; the coarse colour is never composited, volume_renderer.py:385-397), so
+ * d loss / d raw_coarse has identically zero rgb columns and the gradients of rgb_linear, views_linears.0 and
+ * feature_linear of the coarse sub-model are exactly zero.  With NERF_PREC_F32 these entries skip that branch: the forward
+ * stops after the sigma head (raw = (0, 0, 0, sigma); feature / views rows are not stored), the backward starts at
+ * g_h7 = w_alpha * g_sigma and leaves the three colour gradients as zeroed by the caller.  `draw`'s rgb columns are not
+ * read.  `save` from the density forward must go to the density backward.  NERF_PREC_F32X: same as the full calls. */
+int32_t nerf_mlp_forward_rays_save_density(const float* rays_o, const float* rays_d, const float* tvals,
+                                           int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
+                                           const void* packed, float* raw, float* save, int32_t precision, void* stream);
+int32_t nerf_mlp_backward_density(const float* rays_o, const float* rays_d, const float* tvals, int64_t t_ray_stride,
+                                  int64_t n_rays, int32_t n_samples, const void* packed_bwd, const float* draw,
+                                  const float* save, float* gsave, float* g_t, float* const grads[24], int32_t precision,
+                                  void* stream);
+
 /* Point-mode twins of the two calls above, for Network.forward itself under autograd (network.py:199-258: explicit
  * `inputs` [n_rays, n_samples, 3] and `viewdirs` [n_rays, 3] used AS GIVEN, no normalisation -- not o + d t):
  * nerf_mlp_forward_points_save = nerf_mlp_forward + the activation store; nerf_mlp_backward_points adds the 24

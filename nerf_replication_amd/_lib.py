@@ -40,6 +40,10 @@ _PROTOS = {
     "nerf_pack_model_bwd": (_c.c_int32, [_c.POINTER(_c.c_void_p), _F, _c.c_int32, _c.c_void_p]),
     "nerf_mlp_backward": (_c.c_int32, [_F, _F, _F, _c.c_int64, _c.c_int64, _c.c_int32, _F, _F, _F, _F, _F,
                                        _c.POINTER(_c.c_void_p), _c.c_int32, _c.c_void_p]),
+    "nerf_mlp_forward_rays_save_density": (_c.c_int32, [_F, _F, _F, _c.c_int64, _c.c_int64, _c.c_int32, _F, _F, _F, _c.c_int32,
+                                                        _c.c_void_p]),
+    "nerf_mlp_backward_density": (_c.c_int32, [_F, _F, _F, _c.c_int64, _c.c_int64, _c.c_int32, _F, _F, _F, _F, _F,
+                                               _c.POINTER(_c.c_void_p), _c.c_int32, _c.c_void_p]),
     "nerf_mlp_forward_points_save": (_c.c_int32, [_F, _F, _c.c_int64, _c.c_int32, _F, _F, _F, _c.c_int32, _c.c_void_p]),
     "nerf_mlp_backward_points": (_c.c_int32, [_F, _c.c_int64, _c.c_int32, _F, _F, _F, _F, _F,
                                               _c.POINTER(_c.c_void_p), _c.c_int32, _c.c_void_p]),

@@ -1151,6 +1151,7 @@ int32_t nerf_pack_model_bwd(const float* const params[24], void* packed_bwd_v, i
 // grads[24]: device pointers in state_dict order (nn.Linear layouts), accumulated into (caller zeroes them)
 // shared by the ray-mode and the point-mode entry: data-gradient chain, then the weight / bias gradients
 static int32_t mlp_backward_impl(const BwdArgs& a, bool pts_mode, float* const grads[24], int32_t precision, void* stream) {
+  const bool dens = a.density_only != 0 && precision == NERF_PREC_F32;    // (the split-fp16 chain computes the colour branch regardless)
   const long long P = a.n_points;
   const float* draw = a.draw; const float* save = a.save; float* gsave = a.gsave;
   int rc;
@@ -1180,10 +1181,13 @@ static int32_t mlp_backward_impl(const BwdArgs& a, bool pts_mode, float* const g
   const float* gf = gsave + TrainGrad::off_gf(P);
   using namespace nerf;
 #define WG(...) do { rc = nerf_wgrad(__VA_ARGS__, P, stream); if (rc) return rc; } while (0)
-  WG(draw, 4, 0, 3, hv, 128, 0, 128, grads[P_WR], 128, 0, grads[P_BR]);                 // rgb_linear
+  // density only: the gradients of rgb_linear, views_linears.0 and feature_linear are identically zero (left as zeroed by the caller)
+  if (!dens) WG(draw, 4, 0, 3, hv, 128, 0, 128, grads[P_WR], 128, 0, grads[P_BR]);      // rgb_linear
   WG(draw, 4, 3, 1, H(7), 256, 0, 256, grads[P_WA], 256, 0, grads[P_BA]);               // alpha_linear
-  WG(gzv, 128, 0, 128, f, 256, 0, 256, grads[P_WV], 283, 0, grads[P_BV]);               // views_linears.0 [feature | dirs]
-  WG(gzv, 128, 0, 128, dpe, 32, 0, 27, grads[P_WV], 283, 256, nullptr);
+  if (!dens) {
+    WG(gzv, 128, 0, 128, f, 256, 0, 256, grads[P_WV], 283, 0, grads[P_BV]);             // views_linears.0 [feature | dirs]
+    WG(gzv, 128, 0, 128, dpe, 32, 0, 27, grads[P_WV], 283, 256, nullptr);
+  }
   WG(GZ(5), 256, 0, 256, pe, 64, 0, 63, grads[10], 319, 0, grads[11]);                  // skip layer, PE part (+ bias)
   WG(GZ(0), 256, 0, 256, pe, 64, 0, 63, grads[P_W0], 63, 0, grads[P_B0]);
   if (precision == NERF_PREC_F32X) {
@@ -1215,7 +1219,7 @@ static int32_t mlp_backward_impl(const BwdArgs& a, bool pts_mode, float* const g
       j.dz = dz; j.ldz = 256; j.zc0 = 0; j.n_out = 256; j.hin = hin; j.ldh = 256; j.hc0 = 0; j.n_in = 256;
       j.dw = dw; j.ldw = ldw; j.wc0 = wc0; j.db = db; j.n_points = P; j.osplit = 2; j.isplit = 2;
     };
-    job(gf, H(7), grads[P_WF], 256, 0, grads[P_BF]);
+    if (!dens) job(gf, H(7), grads[P_WF], 256, 0, grads[P_BF]);
     for (int l = 7; l >= 1; --l) {
       if (l == 5) job(GZ(5), H(4), grads[10], 319, 63, nullptr);
       else job(GZ(l), H(l - 1), grads[2 * l], 256, 0, grads[2 * l + 1]);
@@ -1226,7 +1230,7 @@ static int32_t mlp_backward_impl(const BwdArgs& a, bool pts_mode, float* const g
     rc = check_launch("nerf_wgrad256_f32_asm_kernel");
     if (rc) return rc;
   } else {
-    WG(gf, 256, 0, 256, H(7), 256, 0, 256, grads[P_WF], 256, 0, grads[P_BF]);           // feature_linear
+    if (!dens) WG(gf, 256, 0, 256, H(7), 256, 0, 256, grads[P_WF], 256, 0, grads[P_BF]);   // feature_linear
     for (int l = 7; l >= 1; --l) {
       if (l == 5) WG(GZ(5), 256, 0, 256, H(4), 256, 0, 256, grads[10], 319, 63, nullptr);   // skip layer, hidden part
       else WG(GZ(l), 256, 0, 256, H(l - 1), 256, 0, 256, grads[2 * l], 256, 0, grads[2 * l + 1]);
@@ -1251,6 +1255,22 @@ int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float*
   return mlp_backward_impl(a, false, grads, precision, stream);
 }
 
+int32_t nerf_mlp_backward_density(const float* rays_o, const float* rays_d, const float* tvals, int64_t t_ray_stride,
+                                  int64_t n_rays, int32_t n_samples, const void* packed_bwd_v, const float* draw,
+                                  const float* save, float* gsave, float* g_t, float* const grads[24], int32_t precision,
+                                  void* stream) {
+  if (n_rays < 0 || n_samples <= 0 || t_ray_stride < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_backward_density: bad size");
+  if (n_rays == 0) return NERF_OK;
+  if (!rays_o || !rays_d || !tvals || !packed_bwd_v || !draw || !save || !gsave || !grads)
+    return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_backward_density: null argument");
+  for (int i = 0; i < 24; ++i) if (!grads[i]) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_backward_density: null gradient pointer");
+  BwdArgs a{};
+  a.rays_o = rays_o; a.rays_d = rays_d; a.tvals = tvals; a.t_ray_stride = t_ray_stride; a.n_points = n_rays * n_samples;
+  a.n_samples = n_samples; a.packed_bwd = (const float*)packed_bwd_v; a.draw = draw; a.save = save; a.gsave = gsave; a.g_t = g_t;
+  a.density_only = 1;
+  return mlp_backward_impl(a, false, grads, precision, stream);
+}
+
 int32_t nerf_mlp_backward_points(const float* pts, int64_t n_rays, int32_t n_samples, const void* packed_bwd_v,
                                  const float* draw, const float* save, float* gsave, float* g_pts,
                                  float* const grads[24], int32_t precision, void* stream) {
@@ -1267,15 +1287,16 @@ int32_t nerf_mlp_backward_points(const float* pts, int64_t n_rays, int32_t n_sam
 
 int64_t nerf_train_save_floats(int64_t n_points) { return n_points < 0 ? -1 : TrainSave::floats(n_points); }
 
-int32_t nerf_mlp_forward_rays_save(const float* rays_o, const float* rays_d, const float* tvals,
-                                   int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
-                                   const void* packed, float* raw, float* save, int32_t precision, void* stream) {
+static int32_t forward_rays_save_impl(const float* rays_o, const float* rays_d, const float* tvals,
+                                      int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
+                                      const void* packed, float* raw, float* save, int32_t precision, void* stream, int density_only) {
   if (n_rays < 0 || n_samples <= 0 || t_ray_stride < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_rays_save: bad size");
   if (n_rays == 0) return NERF_OK;
   if (!rays_o || !rays_d || !tvals || !packed || !raw || !save) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_rays_save: null argument");
   MlpArgs a{};
   a.rays_o = rays_o; a.rays_d = rays_d; a.tvals = tvals; a.t_ray_stride = t_ray_stride;
   a.n_points = n_rays * n_samples; a.n_samples = n_samples; a.packed = (const float*)packed; a.raw = raw; a.save = save;
+  a.density_only = density_only;
   if (precision == NERF_PREC_F32X) {
     const long long n_tiles = (a.n_points + kXTilePts - 1) / kXTilePts;
     const unsigned blocks = (unsigned)(n_tiles < num_cus() ? n_tiles : num_cus());
@@ -1285,8 +1306,21 @@ int32_t nerf_mlp_forward_rays_save(const float* rays_o, const float* rays_d, con
   if (precision != NERF_PREC_F32) return fail(NERF_ERR_UNSUPPORTED, "%s", "nerf_mlp_forward_rays_save: f32 or f32x only");
   const long long tiles = (a.n_points + nerf::kTilePts - 1) / nerf::kTilePts;
   if (tiles > 0x7fffffffLL) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_rays_save: too many points for one launch");
-  hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, true>), dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, a);   // barrier-free: one-wave workgroups
+  // barrier-free: one-wave workgroups
+  if (density_only) hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, true, true>), dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, true>), dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, a);
   return check_launch("nerf_mlp_f32_kernel<save>");
+}
+
+int32_t nerf_mlp_forward_rays_save(const float* rays_o, const float* rays_d, const float* tvals,
+                                   int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
+                                   const void* packed, float* raw, float* save, int32_t precision, void* stream) {
+  return forward_rays_save_impl(rays_o, rays_d, tvals, t_ray_stride, n_rays, n_samples, packed, raw, save, precision, stream, 0);
+}
+int32_t nerf_mlp_forward_rays_save_density(const float* rays_o, const float* rays_d, const float* tvals,
+                                           int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
+                                           const void* packed, float* raw, float* save, int32_t precision, void* stream) {
+  return forward_rays_save_impl(rays_o, rays_d, tvals, t_ray_stride, n_rays, n_samples, packed, raw, save, precision, stream, 1);
 }
 
 int32_t nerf_mlp_forward_points_save(const float* pts, const float* viewdirs, int64_t n_rays, int32_t n_samples,

@@ -38,8 +38,10 @@ class RenderFunction(torch.autograd.Function):
         save_f = torch.empty(int(lib.nerf_train_save_floats(n * S_f)), **f32)
         rgb, depth = torch.empty((n, 3), **f32), torch.empty((n,), **f32)
         with torch.cuda.device(dev):
-            _lib.check(lib.nerf_mlp_forward_rays_save(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t_c), 0, n, S_c,
-                                                      pk_c.data_ptr(), _lib.ptr(raw_c), _lib.ptr(save_c), prec, st), "forward(coarse)")
+            # coarse pass: only its sigma is ever used (it places the fine samples; the coarse colour is never
+            # composited) -> the density-only forward / backward pair
+            _lib.check(lib.nerf_mlp_forward_rays_save_density(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t_c), 0, n, S_c,
+                                                              pk_c.data_ptr(), _lib.ptr(raw_c), _lib.ptr(save_c), prec, st), "forward(coarse)")
             _lib.check(lib.nerf_sample_fine(_lib.ptr(raw_c), _lib.ptr(t_c), _lib.ptr(u), n, _lib.ptr(t_sorted), None, None,
                                             0.0, 0.0, st), "nerf_sample_fine")
             _lib.check(lib.nerf_mlp_forward_rays_save(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t_sorted), S_f, n, S_f,
@@ -95,9 +97,9 @@ class RenderFunction(torch.autograd.Function):
                                                      _lib.ptr(g_t), _lib.ptr(g_raw_c), st), "nerf_sample_fine_backward")
             _lib.check(lib.nerf_pack_model_bwd(_ptr_array([p.detach().contiguous() for p in params[:24]]), pk_b.data_ptr(), prec, st))
             gsave_c = gsave[: int(lib.nerf_train_grad_floats(n * S_c))]
-            _lib.check(lib.nerf_mlp_backward(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t_c), 0, n, S_c,
-                                             pk_b.data_ptr(), _lib.ptr(g_raw_c), _lib.ptr(save_c), _lib.ptr(gsave_c),
-                                             None, _ptr_array(grads[:24]), prec, st), "nerf_mlp_backward(coarse)")
+            _lib.check(lib.nerf_mlp_backward_density(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t_c), 0, n, S_c,
+                                                     pk_b.data_ptr(), _lib.ptr(g_raw_c), _lib.ptr(save_c), _lib.ptr(gsave_c),
+                                                     None, _ptr_array(grads[:24]), prec, st), "nerf_mlp_backward(coarse)")
         return (None, None, None) + tuple(g.to(p.dtype) for g, p in zip(grads, params))
 
 
