@@ -416,3 +416,49 @@ def test_network_forward_is_differentiable(amd, oracle, synthetic_sd, model, pre
     assert p_hip.grad is not None and torch.isfinite(p_hip.grad).all()
     with pytest.raises(NotImplementedError):
         net(p_hip, vd.cuda().requires_grad_(True), None, model)
+
+
+def test_density_only_pair_equals_full_pair_with_zero_colour_gradient(amd, net, synthetic_sd):
+    """The coarse pass of a training step runs nerf_mlp_forward_rays_save_density / nerf_mlp_backward_density (the colour
+    branch is computed by the reference but never used: SURVEY F6/F10).  Against the full pair fed a d loss / d raw with
+    zero rgb columns: sigma bit-identical, the 18 trunk / alpha gradients and d loss / d t equal to rounding (the
+    weight-gradient kernels accumulate with atomics), the colour-branch gradients EXACTLY zero in both."""
+    import ctypes
+    lib, L = amd._lib.load(), amd._lib
+    gen = torch.Generator().manual_seed(23)
+    n, S = 41, 64
+    o = torch.tensor([0.0, 0.0, 4.0]).expand(n, 3).contiguous().cuda()
+    d = torch.randn(n, 3, generator=gen) * 0.2 + torch.tensor([0.0, 0.0, -1.0])
+    d = (d / d.norm(dim=-1, keepdim=True)).contiguous().cuda()
+    t_c = torch.linspace(2.0, 6.0, S).cuda()
+    G = torch.randn(n, S, 4, generator=gen) * 1e-3
+    G[..., :3] = 0.0
+    G = G.cuda().contiguous()
+    params = [p.detach().contiguous() for p in net.model.ordered_params()]
+    arr = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in params])
+    st = L.stream_of(o.device)
+    pk_b = torch.empty(int(lib.nerf_packed_bwd_bytes(0)), dtype=torch.uint8, device="cuda")
+    L.check(lib.nerf_pack_model_bwd(arr, pk_b.data_ptr(), 0, st))
+    P = n * S
+    out = {}
+    for tag, fwd, bwd in (("full", lib.nerf_mlp_forward_rays_save, lib.nerf_mlp_backward),
+                          ("density", lib.nerf_mlp_forward_rays_save_density, lib.nerf_mlp_backward_density)):
+        raw = torch.full((n, S, 4), float("nan"), device="cuda")
+        save = torch.empty(int(lib.nerf_train_save_floats(P)), device="cuda")
+        gsave = torch.empty(int(lib.nerf_train_grad_floats(P)), device="cuda")
+        g_t = torch.empty(n, S, device="cuda")
+        grads = [torch.zeros_like(p) for p in params]
+        L.check(fwd(L.ptr(o), L.ptr(d), L.ptr(t_c), 0, n, S, net.packed("").data_ptr(), L.ptr(raw), L.ptr(save), 0, st))
+        L.check(bwd(L.ptr(o), L.ptr(d), L.ptr(t_c), 0, n, S, pk_b.data_ptr(), L.ptr(G), L.ptr(save), L.ptr(gsave), L.ptr(g_t),
+                    _grad_ptrs(amd, grads), 0, st))
+        torch.cuda.synchronize()
+        out[tag] = (raw, g_t, grads)
+    assert torch.equal(out["full"][0][..., 3], out["density"][0][..., 3])
+    assert torch.all(out["density"][0][..., :3] == 0)
+    assert _rel(out["density"][1], out["full"][1].cpu()) <= 1e-6
+    names = list(__import__("nerf_oracle").SUBMODEL_KEYS)
+    for name, gf, gd in zip(names, out["full"][2], out["density"][2]):
+        if name.startswith(("views_linears", "feature_linear", "rgb_linear")):
+            assert torch.all(gf == 0) and torch.all(gd == 0), name
+        else:
+            assert gf.abs().max() > 0 and _rel(gd, gf.cpu()) <= 2e-6, name
