@@ -133,12 +133,17 @@ int32_t nerf_mlp_backward_density(const float* rays_o, const float* rays_d, cons
  * `inputs` [n_rays, n_samples, 3] and `viewdirs` [n_rays, 3] used AS GIVEN, no normalisation -- not o + d t):
  * nerf_mlp_forward_points_save = nerf_mlp_forward + the activation store; nerf_mlp_backward_points adds the 24
  * parameter gradients and, if `g_pts` [P,3] is given, writes d loss / d inputs (through the positional encoding).
- * d loss / d viewdirs is not produced (no caller of the reference differentiates the ray directions). */
+ * d loss / d viewdirs comes from nerf_viewdirs_backward below (a separate, tiny launch: no caller of the reference needs it). */
 int32_t nerf_mlp_forward_points_save(const float* pts, const float* viewdirs, int64_t n_rays, int32_t n_samples,
                                      const void* packed, float* raw, float* save, int32_t precision, void* stream);
 int32_t nerf_mlp_backward_points(const float* pts, int64_t n_rays, int32_t n_samples, const void* packed_bwd,
                                  const float* draw, const float* save, float* gsave, float* g_pts,
                                  float* const grads[24], int32_t precision, void* stream);
+/* d loss / d viewdirs [n_rays,3] of the Network.forward call whose backward just filled `gsave` (either chain): the ray's
+ * direction reaches views_linears.0 through its 27-channel encoding, shared by the ray's samples.  `w_views` is the raw
+ * views_linears.0.weight [128,283] (nn.Linear layout), `viewdirs` the forward's [n_rays,3]. */
+int32_t nerf_viewdirs_backward(const float* gsave, int64_t n_rays, int32_t n_samples, const float* w_views,
+                               const float* viewdirs, float* g_viewdirs, void* stream);
 
 /* Adjoint of nerf_composite (autograd of volume_renderer.py:414-432 with :67-96): g_rgb [n,3], g_depth [n]
  * (nullable) -> g_raw [n,S,4] and, if given, g_t [n,S] (the direct dependence of the image on the sample

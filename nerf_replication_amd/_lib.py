@@ -47,6 +47,7 @@ _PROTOS = {
     "nerf_mlp_forward_points_save": (_c.c_int32, [_F, _F, _c.c_int64, _c.c_int32, _F, _F, _F, _c.c_int32, _c.c_void_p]),
     "nerf_mlp_backward_points": (_c.c_int32, [_F, _c.c_int64, _c.c_int32, _F, _F, _F, _F, _F,
                                               _c.POINTER(_c.c_void_p), _c.c_int32, _c.c_void_p]),
+    "nerf_viewdirs_backward": (_c.c_int32, [_F, _c.c_int64, _c.c_int32, _F, _F, _F, _c.c_void_p]),
     "nerf_wgrad": (_c.c_int32, [_F, _c.c_int64, _c.c_int32, _c.c_int32, _F, _c.c_int64, _c.c_int32, _c.c_int32, _F,
                                 _c.c_int64, _c.c_int32, _F, _c.c_int64, _c.c_void_p]),
     "nerf_train_save_floats": (_c.c_int64, [_c.c_int64]),

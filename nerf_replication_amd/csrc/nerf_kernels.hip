@@ -830,6 +830,40 @@ void nerf_ssim_kernel(const float* __restrict__ pred, const float* __restrict__ 
   if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
 }
 
+// ------------------------------------------------------------------------------------ d loss / d viewdirs (Network.forward under autograd)
+// The view direction of a ray enters views_linears.0 through its 27-channel encoding (network.py:224-225, :63-66) and is
+// shared by the ray's samples: g_dir_enc = W_v[:, 256:283]^T (sum_s g_zv[ray, s]), then the chain rule through
+// [d, sin(2^k d), cos(2^k d)] (freq.py:31-32).  One 128-thread workgroup per ray; 3.5 k MACs per ray -- negligible.
+__global__ __launch_bounds__(128)
+void nerf_viewdirs_bwd_kernel(const float* __restrict__ gzv, long long n_rays, int n_samples, const float* __restrict__ w_views,
+                              const float* __restrict__ viewdirs, float* __restrict__ g_viewdirs) {
+  __shared__ float G[128];
+  __shared__ float E[27];
+  const long long ray = blockIdx.x;
+  const int o = threadIdx.x;
+  float acc = 0.0f;
+  for (int s = 0; s < n_samples; ++s) acc += gzv[(ray * n_samples + s) * 128 + o];
+  G[o] = acc;
+  __syncthreads();
+  if (o < 27) {
+    float e = 0.0f;
+    for (int k = 0; k < 128; ++k) e = fmaf(G[k], w_views[k * 283 + 256 + o], e);
+    E[o] = e;
+  }
+  __syncthreads();
+  if (o < 3) {
+    const float d = viewdirs[ray * 3 + o];
+    float g = E[o];
+    for (int k = 0; k < 4; ++k) {
+      const float f = (float)(1 << k);
+      float sv, cv;
+      sincosf(d * f, &sv, &cv);
+      g += f * (cv * E[3 + 6 * k + o] - sv * E[3 + 6 * k + 3 + o]);
+    }
+    g_viewdirs[ray * 3 + o] = g;
+  }
+}
+
 // ------------------------------------------------------------------------------------ launch helpers
 int num_cus() {
   static int cus = 0;
@@ -1092,6 +1126,17 @@ int32_t nerf_sample_fine_backward(const float* raw_coarse, const float* t_coarse
   hipLaunchKernelGGL(nerf_sample_bwd_kernel, dim3((unsigned)((n_rays + kSampleThreads - 1) / kSampleThreads)), dim3(kSampleThreads), 0,
                      (hipStream_t)stream, raw_coarse, t_coarse, u, (long long)n_rays, t_sorted, g_t_sorted, g_raw_coarse);
   return check_launch("nerf_sample_bwd_kernel");
+}
+
+int32_t nerf_viewdirs_backward(const float* gsave, int64_t n_rays, int32_t n_samples, const float* w_views,
+                               const float* viewdirs, float* g_viewdirs, void* stream) {
+  if (n_rays < 0 || n_samples <= 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_viewdirs_backward: bad size");
+  if (n_rays == 0) return NERF_OK;
+  if (!gsave || !w_views || !viewdirs || !g_viewdirs) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_viewdirs_backward: null argument");
+  if (n_rays > 0x7fffffffLL) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_viewdirs_backward: too many rays for one launch");
+  hipLaunchKernelGGL(nerf_viewdirs_bwd_kernel, dim3((unsigned)n_rays), dim3(128), 0, (hipStream_t)stream,
+                     gsave + TrainGrad::off_gzv(n_rays * n_samples), (long long)n_rays, n_samples, w_views, viewdirs, g_viewdirs);
+  return check_launch("nerf_viewdirs_bwd_kernel");
 }
 
 int32_t nerf_adam_step(int32_t n_tensors, float* const params[], const float* const grads[], float* const exp_avg[],

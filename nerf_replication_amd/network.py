@@ -130,14 +130,11 @@ class Network(nn.Module):
 
         Differentiable like the reference's: with autograd on and either `inputs.requires_grad` or a `.train()` network
         whose parameters require grad, the forward runs the SAVE-mode fused kernel and backward() the adjoint HIP
-        kernels (nerf_mlp_backward_points): gradients w.r.t. the 24 tensors of the selected sub-model and w.r.t.
-        `inputs`.  (`viewdirs` are constants of the rays in every caller of the reference; their gradient is not built.)"""
+        kernels (nerf_mlp_backward_points, nerf_viewdirs_backward): gradients w.r.t. the 24 tensors of the selected
+        sub-model, `inputs` and `viewdirs`."""
         sub = self.model_fine if model == "fine" else self.model
         if torch.is_grad_enabled() and (inputs.requires_grad or
                                         (self.training and any(p.requires_grad for p in sub.parameters()))):
-            if viewdirs.requires_grad:
-                raise NotImplementedError("d raw / d viewdirs is not built (no caller of the reference differentiates the "
-                                          "ray directions); detach viewdirs")
             return self._forward_with_grad(inputs, viewdirs, valid_mask, model, sub)
         lib = _lib.load()
         dev = inputs.device
@@ -171,12 +168,12 @@ class Network(nn.Module):
         n, s = inputs.shape[0], inputs.shape[1]
         params = tuple(sub.ordered_params())
         if valid_mask is None:
-            return _MlpFunction.apply(self, model, inputs.to(torch.float32), viewdirs.detach().to(torch.float32), *params)
+            return _MlpFunction.apply(self, model, inputs.to(torch.float32), viewdirs.to(torch.float32), *params)
         # masked (network.py:207-214, :238-253): the valid points as m one-sample rays; the scatter back into zeros is
         # index plumbing whose adjoint (a gather) torch provides
         flat = valid_mask.reshape(-1)
         pts = inputs.to(torch.float32).reshape(-1, 3)[flat][:, None, :]
-        dirs = viewdirs.detach().to(torch.float32)[:, None].expand(n, s, 3).reshape(-1, 3)[flat]
+        dirs = viewdirs.to(torch.float32)[:, None].expand(n, s, 3).reshape(-1, 3)[flat]      # (its adjoint sums over samples)
         out = torch.zeros((n * s, 4), dtype=torch.float32, device=inputs.device)
         if pts.shape[0] > 0:
             out = out.index_put((flat.nonzero(as_tuple=True)[0],), _MlpFunction.apply(self, model, pts, dirs, *params)[:, 0])
@@ -204,13 +201,13 @@ class _MlpFunction(torch.autograd.Function):
                                                             _lib.ptr(raw), _lib.ptr(save), prec, _lib.stream_of(dev)),
                            "nerf_mlp_forward_points_save")
         ctx.prec, ctx.shape, ctx.params = prec, (n, s), params
-        ctx.save_for_backward(pts, save)
+        ctx.save_for_backward(pts, save, dirs)
         return raw
 
     @staticmethod
     def backward(ctx, g_raw):
         lib = _lib.load()
-        pts, save = ctx.saved_tensors
+        pts, save, dirs = ctx.saved_tensors
         params, (n, s), prec = ctx.params, ctx.shape, ctx.prec
         dev = pts.device
         st = _lib.stream_of(dev)
@@ -232,7 +229,15 @@ class _MlpFunction(torch.autograd.Function):
                 _lib.check(lib.nerf_mlp_backward_points(_lib.ptr(pts), n, s, pk_b.data_ptr(), _lib.ptr(g_raw), _lib.ptr(save),
                                                         _lib.ptr(gsave), None if g_pts is None else _lib.ptr(g_pts), garr,
                                                         prec, st), "nerf_mlp_backward_points")
-        return (None, None, g_pts, None) + tuple(g.to(p.dtype) if p.requires_grad else None for g, p in zip(grads, params))
+        g_dirs = None
+        if ctx.needs_input_grad[3]:
+            g_dirs = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+            if n * s > 0:
+                w_views = params[16].detach().contiguous()          # views_linears.0.weight [128, 283]
+                with torch.cuda.device(dev):
+                    _lib.check(lib.nerf_viewdirs_backward(_lib.ptr(gsave), n, s, _lib.ptr(w_views), _lib.ptr(dirs),
+                                                          _lib.ptr(g_dirs), st), "nerf_viewdirs_backward")
+        return (None, None, g_pts, g_dirs) + tuple(g.to(p.dtype) if p.requires_grad else None for g, p in zip(grads, params))
 
 
 def positional_encoding(x, n_freqs):

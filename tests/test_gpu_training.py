@@ -364,7 +364,7 @@ def test_checkpoint_resume_continues_bit_identically(amd, tmp_path):
 @pytest.mark.parametrize("model,prefix", [("fine", "model_fine"), ("", "model")])
 def test_network_forward_is_differentiable(amd, oracle, synthetic_sd, model, prefix, precision):
     """Network.forward itself under autograd (reference: network.py:199-258 is an ordinary differentiable module):
-    loss = sum(raw * G) -> gradients of the 24 tensors of the selected sub-model AND of `inputs`, against
+    loss = sum(raw * G) -> gradients of the 24 tensors of the selected sub-model AND of `inputs` and `viewdirs`, against
     oracle.network_forward under torch autograd.  viewdirs are deliberately NOT unit length: Network.forward uses them
     as given (only the renderer normalises, volume_renderer.py:314).  Also the masked (ESS/ERT) call."""
     gen = torch.Generator().manual_seed(17)
@@ -384,14 +384,16 @@ def test_network_forward_is_differentiable(amd, oracle, synthetic_sd, model, pre
         # ---- oracle
         sd = {k: v.clone().requires_grad_(k.startswith(prefix + ".")) for k, v in synthetic_sd.items()}
         p_ref = pts.clone().requires_grad_(True)
-        raw_ref = oracle.network_forward(sd, p_ref, vd, model)
+        vd_ref = vd.clone().requires_grad_(True)
+        raw_ref = oracle.network_forward(sd, p_ref, vd_ref, model)
         if msk is not None:
             raw_ref = raw_ref * msk[..., None]                # network.py:238-253: zeros where masked out
         (raw_ref * G).sum().backward()
         # ---- HIP through nn.Module.__call__
         net.zero_grad(set_to_none=True)
         p_hip = pts.cuda().requires_grad_(True)
-        raw = net(p_hip, vd.cuda(), None if msk is None else msk.cuda(), model)
+        vd_hip = vd.cuda().requires_grad_(True)
+        raw = net(p_hip, vd_hip, None if msk is None else msk.cuda(), model)
         assert raw.requires_grad and raw.shape == (n, S, 4)
         (raw * G.cuda()).sum().backward()
         assert _rel(raw.detach(), raw_ref.detach()) <= 2e-5
@@ -402,11 +404,13 @@ def test_network_forward_is_differentiable(amd, oracle, synthetic_sd, model, pre
             assert err <= 1e-5, (tag, name, err)         # measured <= 1.3e-6
         e_x = _rel(p_hip.grad, p_ref.grad)
         assert e_x <= 1e-5, (tag, e_x)
+        e_d = _rel(vd_hip.grad, vd_ref.grad)                                  # d / d viewdirs (nerf_viewdirs_backward)
+        assert vd_hip.grad.shape == (n, 3) and e_d <= 1e-5, (tag, e_d)
         assert all(p.grad is None for p in other.parameters())               # the other sub-model is not touched
         if msk is not None:
             assert torch.all(p_hip.grad.cpu()[~msk] == 0) and torch.all(raw.detach().cpu()[~msk] == 0)
         parity_record("gradients", f"network_forward_autograd/{prefix}/{precision}/{tag}",
-                      {"worst_param_rel_err": worst, "d_inputs_rel_err": e_x})
+                      {"worst_param_rel_err": worst, "d_inputs_rel_err": e_x, "d_viewdirs_rel_err": e_d})
     # eval() + no_grad stays the inference kernel; grad w.r.t. inputs alone works on an eval() network too
     net.eval()
     with torch.no_grad():
@@ -414,8 +418,6 @@ def test_network_forward_is_differentiable(amd, oracle, synthetic_sd, model, pre
     p_hip = pts.cuda().requires_grad_(True)
     net(p_hip, vd.cuda(), None, model).sum().backward()
     assert p_hip.grad is not None and torch.isfinite(p_hip.grad).all()
-    with pytest.raises(NotImplementedError):
-        net(p_hip, vd.cuda().requires_grad_(True), None, model)
 
 
 def test_density_only_pair_equals_full_pair_with_zero_colour_gradient(amd, net, synthetic_sd):
