@@ -166,7 +166,8 @@ def run_training(pkg, sd, dev, precision, steps, warmup, world, rank):
     # feature 256x256, views 283x128, rgb 128x3 = 204 288 FLOP per point -- is computed by the reference but never used,
     # SURVEY F6/F10, and skipped here): the roofline counts the FLOP actually executed, not the reference's
     flop_ref = n_rays * POINTS_PER_RAY * FLOP_PER_POINT * 3.0
-    skipped = n_rays * 64 * 204288 * 3.0 if precision == "f32" else 0.0
+    # (f32x: its chain kernels still run the coarse colour branch -- on zeros --, only the three weight-gradient jobs are skipped)
+    skipped = n_rays * 64 * 204288 * (3.0 if precision == "f32" else 1.0)
     flop = flop_ref - skipped
     # f32x: three fp16 (or six bf16) MFMAs per algorithmic MAC -> ceiling = a third of the fp16 peak
     peak = PEAK_F32_MFMA if precision == "f32" else PEAK_F16_MFMA / 3.0

@@ -1196,7 +1196,9 @@ int32_t nerf_pack_model_bwd(const float* const params[24], void* packed_bwd_v, i
 // grads[24]: device pointers in state_dict order (nn.Linear layouts), accumulated into (caller zeroes them)
 // shared by the ray-mode and the point-mode entry: data-gradient chain, then the weight / bias gradients
 static int32_t mlp_backward_impl(const BwdArgs& a, bool pts_mode, float* const grads[24], int32_t precision, void* stream) {
-  const bool dens = a.density_only != 0 && precision == NERF_PREC_F32;    // (the split-fp16 chain computes the colour branch regardless)
+  // density only: the fp32 chain skips the colour branch in the kernel; the split-fp16 chain computes it (on zeros), but its
+  // three weight-gradient jobs are skipped on the host all the same: their result is exactly zero either way
+  const bool dens = a.density_only != 0;
   const long long P = a.n_points;
   const float* draw = a.draw; const float* save = a.save; float* gsave = a.gsave;
   int rc;
@@ -1243,7 +1245,7 @@ static int32_t mlp_backward_impl(const BwdArgs& a, bool pts_mode, float* const g
       WgradXJob& j = w.job[w.n_jobs++];
       j.dz = dz; j.hin = hin; j.dw = dw; j.db = db; j.ldz = 256; j.zc0 = 0; j.ldh = 256; j.hc0 = 0; j.ldw = ldw; j.wc0 = wc0;   // ld 256: the kernel assumes 1-KiB rows
     };
-    job(gf, H(7), grads[P_WF], 256, 0, grads[P_BF]);
+    if (!dens) job(gf, H(7), grads[P_WF], 256, 0, grads[P_BF]);
     for (int l = 7; l >= 1; --l) {
       if (l == 5) job(GZ(5), H(4), grads[10], 319, 63, nullptr);
       else job(GZ(l), H(l - 1), grads[2 * l], 256, 0, grads[2 * l + 1]);
