@@ -719,3 +719,39 @@ def test_bench_two_rank_path_on_one_gpu():
     assert "error" not in out["training"] and out["training"]["n_gpus"] == 2
     assert out["training"]["f32"]["rays_per_iter_per_gpu"] == 4096 and out["training"]["f32x"]["ms_per_step"] > 0
     assert "error" not in out["config5"] and out["config5"]["finite"] and out["config5"]["n_gpus"] == 2
+
+
+@pytest.mark.parametrize("family", ["base", "sharp", "white"])
+def test_family_parity_large_sample(amd, oracle, synthetic_sd, family):
+    """The attributed-parity criteria of test_family_parity_attributed on a larger sample: 4096 random pixels of an 800x800 frame
+    per scene family, against the CPU oracle (bit-exact to the real reference on the family fixtures, test_oracle_golden.py).
+    The point is the STATISTICS -- rays outside the SURVEY tolerance, moved samples, attribution maxima -- which go to
+    profiles/parity_r02.json; the assertions are the same family bounds."""
+    sd = oracle.weight_family(synthetic_sd, family)
+    net = amd.Network()
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    n = 4096
+    ids = torch.randperm(800 * 800, generator=torch.Generator().manual_seed(77))[:n]
+    o, d = oracle.pinhole_rays(800, 800, oracle.camera_pose(140.0, -25.0), pixel_ids=ids)
+    with torch.no_grad():
+        ref_rgb, ref_dep, parts = oracle.render(sd, o[None], d[None], return_parts=True)
+    oc, dc = o.cuda(), d.cuda()
+    hip = _hip_stages(amd, net, oc, dc)
+    st, over = image_stats(oracle, hip["rgb"], hip["depth"], ref_rgb, ref_dep)
+    dt = (hip["t_sorted"].cpu() - parts["t_sorted"]).abs()
+    st["samples_moved_gt_1e-4"] = int((dt > 1e-4).sum())
+    st["rays_with_move_gt_1e-4"] = int((dt.max(1).values > 1e-4).sum())
+    st["max_sample_move"] = dt.max().item()
+    st["rays_over_tolerance_without_moved_sample"] = int((over & ~(dt.max(1).values > 1e-5)).sum())
+    att = _hip_stages(amd, net, oc, dc, t_sorted_override=parts["t_sorted"])
+    a_st, _ = image_stats(oracle, att["rgb"], att["depth"], ref_rgb, ref_dep)
+    st["attributed_on_reference_depths"] = dict(rgb_max=a_st["rgb_max"], depth_max=a_st["depth_max"],
+                                                rays_over_tolerance=a_st["rays_over_tolerance"])
+    parity_record("family_parity_attributed", f"{family}/frame4096/f32", st)
+    print(family, st)
+    assert a_st["rgb_max"] <= 2e-5 and a_st["depth_max"] <= 2e-4, st
+    assert st["rays_over_tolerance"] <= MAX_OVER_FRAC[family] * n, st
+    assert st["psnr_db"] >= {"base": 95.0, "sharp": 95.0, "white": 58.0}[family], st
+    if family != "white":
+        assert st["rays_over_tolerance_without_moved_sample"] == 0, st
