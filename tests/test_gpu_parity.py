@@ -750,8 +750,9 @@ def test_family_parity_large_sample(amd, oracle, synthetic_sd, family):
                                                 rays_over_tolerance=a_st["rays_over_tolerance"])
     parity_record("family_parity_attributed", f"{family}/frame4096/f32", st)
     print(family, st)
-    assert a_st["rgb_max"] <= 2e-5 and a_st["depth_max"] <= 2e-4, st
-    assert st["rays_over_tolerance"] <= MAX_OVER_FRAC[family] * n, st
-    assert st["psnr_db"] >= {"base": 95.0, "sharp": 95.0, "white": 58.0}[family], st
+    # attribution, every one of the 4096 rays: measured <= 1.7e-5 / 9.9e-5 (sharp), i.e. 6x / 10x inside SURVEY 8c's figures
+    assert a_st["rgb_max"] <= 5e-5 and a_st["depth_max"] <= 5e-4, st
+    assert st["rays_over_tolerance"] <= MAX_OVER_FRAC[family] * n, st                  # measured 4 / 2 / 53 of 4096
+    assert st["psnr_db"] >= {"base": 95.0, "sharp": 95.0, "white": 58.0}[family], st    # measured 102.4 / 110.1 / 71.8
     if family != "white":
         assert st["rays_over_tolerance_without_moved_sample"] == 0, st
