@@ -182,8 +182,12 @@ def family_fixtures(net, ren, base_sd):
     tests can attribute any per-ray deviation to moved samples (inverse-CDF discontinuities)."""
     ids = torch.from_numpy(np.random.default_rng(1).choice(800 * 800, 512, replace=False))
     sets = {"seed": orc.seeded_rays(512, 31), "pin": orc.pinhole_rays(800, 800, orc.camera_pose(55.0), pixel_ids=ids)}
-    for fam in orc.WEIGHT_FAMILIES:
-        net.load_state_dict(orc.weight_family(base_sd, fam), strict=True)
+    # "trained": not a transform but a network TRAINED by the build itself (tools/make_trained_fixture.py: 3000 steps of the
+    # reference's training step on the sharp scene, held-out PSNR 27.4 dB) -- Adam-shaped weights, committed as
+    # tests/golden/trained_ckpt.pth in the reference's {"net": ...} layout
+    trained = torch.load(os.path.join(OUT, "trained_ckpt.pth"), weights_only=True)["net"]
+    for fam in list(orc.WEIGHT_FAMILIES) + ["trained"]:
+        net.load_state_dict(trained if fam == "trained" else orc.weight_family(base_sd, fam), strict=True)
         rec = {}
         with torch.no_grad():
             for tag, (o, d) in sets.items():

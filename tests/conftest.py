@@ -78,3 +78,18 @@ def parity_record(section, key, stats):
         out = os.path.join(REPO, "gpurun_out")
         os.makedirs(out, exist_ok=True)
         shutil.copyfile(PARITY_JSON, os.path.join(out, "parity_r02.json"))
+
+
+FAMILIES = ("base", "sharp", "white", "trained")
+
+
+@pytest.fixture(scope="session")
+def family_sd(oracle, synthetic_sd):
+    """state_dict of a parity scene family: exact transforms of the committed checkpoint (oracle.WEIGHT_FAMILIES), or
+    "trained" = tests/golden/trained_ckpt.pth, a network trained by the build itself (tools/make_trained_fixture.py)."""
+    def get(name):
+        if name == "trained":
+            ck = torch.load(os.path.join(GOLDEN, "trained_ckpt.pth"), weights_only=True)
+            return {k: ck["net"][k] for k in oracle.state_dict_keys()}
+        return oracle.weight_family(synthetic_sd, name)
+    return get

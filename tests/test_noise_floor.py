@@ -42,10 +42,10 @@ def floor_stats(oracle, sd, o, d):
                 over_tolerance_but_no_moved_sample=int((over & ~moved_any).sum()))
 
 
-@pytest.mark.parametrize("family", ["base", "sharp", "white"])
-def test_reference_fp32_vs_fp64_floor(oracle, golden, synthetic_sd, family):
+@pytest.mark.parametrize("family", ["base", "sharp", "white", "trained"])
+def test_reference_fp32_vs_fp64_floor(oracle, golden, family_sd, family):
     g = golden(f"render_family_{family}.npz")
-    sd = oracle.weight_family(synthetic_sd, family)
+    sd = family_sd(family)
     o = torch.cat([g["seed_rays_o"], g["pin_rays_o"]])
     d = torch.cat([g["seed_rays_d"], g["pin_rays_d"]])
     o2, d2 = oracle.seeded_rays(2048, 5)       # more rays for a stable figure (over-tolerance rays are ~1 in 10^3)
@@ -54,8 +54,12 @@ def test_reference_fp32_vs_fp64_floor(oracle, golden, synthetic_sd, family):
     print(f"noise floor [{family}]: {json.dumps(st)}")
     if os.environ.get("PARITY_RECORD"):
         parity_record("noise_floor_reference_fp32_vs_fp64_mlp", family, st)
-    # (1) samples DO move under fp32-level perturbation, on every family
-    assert st["rays_with_moved_samples"] >= 1 and st["max_sample_move"] > 10 * EPS_T
+    # (1) samples DO move under fp32-level perturbation, on every synthetic family.  (Not on "trained": its unsupervised coarse
+    #     network is a smooth fog, so the coarse pdf has no empty bins and the sampler is well conditioned: floor 8e-6 / 5e-5.)
+    if family != "trained":
+        assert st["rays_with_moved_samples"] >= 1 and st["max_sample_move"] > 10 * EPS_T
+    else:
+        assert st["rgb_max"] <= EPS_RGB and st["depth_max"] <= EPS_DEP
     # (2) and whenever a ray leaves the SURVEY tolerance, a moved sample is the cause: rounding alone stays inside
     #     (not asserted on the white-noise field: there the fine network varies on the scale of the 2^9 octave's
     #     wavelength 0.012, so even a 1e-5 move of a sample is visible -- measured: 7e-5 / 9e-4 for unmoved rays)

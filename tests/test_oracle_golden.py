@@ -140,13 +140,14 @@ def test_ess_ert_masked_path(oracle, golden, synthetic_sd):
     assert (rgb2 - g["rgb_thr002"]).abs().max() <= 1e-6 and (dep2 - g["depth_thr002"]).abs().max() <= 1e-5
 
 
-@pytest.mark.parametrize("family", ["base", "sharp", "white"])
-def test_weight_family_renders(oracle, golden, synthetic_sd, family):
+@pytest.mark.parametrize("family", ["base", "sharp", "white", "trained"])
+def test_weight_family_renders(oracle, golden, synthetic_sd, family_sd, family):
     """Round 2: parity scenes beyond the benign band-limited field.  The family state_dicts are exact elementwise
     transforms of the committed checkpoint (bit-reproducible anywhere); the REAL reference rendered them in
-    oracle/gen_golden.py::family_fixtures.  Oracle image and merged sample depths: bit-exact."""
+    oracle/gen_golden.py::family_fixtures; "trained" is a network trained by this build (tests/golden/trained_ckpt.pth).
+    Oracle image and merged sample depths: bit-exact."""
     g = golden(f"render_family_{family}.npz")
-    sd = oracle.weight_family(synthetic_sd, family)
+    sd = family_sd(family)
     for tag in ("seed", "pin"):
         o, d = g[f"{tag}_rays_o"], g[f"{tag}_rays_d"]
         with torch.no_grad():
@@ -159,7 +160,11 @@ def test_weight_family_renders(oracle, golden, synthetic_sd, family):
     # what makes each family what it says: occupancy / sharpness of the coarse density along the fixture rays
     sig = torch.cat([g["seed_sigma_coarse_raw"], g["pin_sigma_coarse_raw"]])
     occ, std = (sig > 0).float().mean().item(), sig.std().item()
-    want = {"base": (0.15, 0.45, 4, 16), "sharp": (0.01, 0.10, 40, 90), "white": (0.15, 0.45, 4, 16)}[family]
+    # ("trained": a network trained by the build on the sharp scene, tools/make_trained_fixture.py: it learned hard surfaces)
+    # ("trained": the reference's step never supervises the coarse network photometrically, and after 3000 steps
+    #  it is a thin, nearly uniform fog -- sigma 0.41 +- 0.16 on 99.9 % of the samples -- while the fine network carries the scene)
+    want = {"base": (0.15, 0.45, 4, 16), "sharp": (0.01, 0.10, 40, 90), "white": (0.15, 0.45, 4, 16), "trained": (0.9, 1.0, 0.05, 1.0)}[family]
+    assert g["pin_rgb"].std() > 0.1 and g["pin_depth"].std() > 0.2          # a scene, not a constant image
     assert want[0] <= occ <= want[1] and want[2] <= std <= want[3], (family, occ, std)
     assert torch.equal(oracle.weight_family(synthetic_sd, "base")["model.alpha_linear.bias"],
                        synthetic_sd["model.alpha_linear.bias"])
