@@ -29,10 +29,12 @@ pytestmark = pytest.mark.gpu
 RAW_RTOL = 2e-5
 EPS_RGB, EPS_DEP = 1e-4, 1e-3            # SURVEY 8c per-ray image tolerance
 # hard per-ray maxima: ~3x the largest value measured on the MI355X for that scene family (profiles/parity_r02.json)
-HARD_MAX = {"base": (8e-4, 3e-3), "sharp": (1e-4, 1e-3), "white": (6e-2, 2.5e-1), "trained": (2e-2, 1e-1)}
+HARD_MAX = {"base": (8e-4, 3e-3), "sharp": (1e-4, 1e-3), "white": (6e-2, 2.5e-1), "trained": (1e-4, 1e-3)}
 # rays allowed outside 1e-4 / 1e-3: base / sharp 1 % (measured <= 1 of 512), white-noise field 3 % (measured 7 of 512;
 # the reference against its own fp64-MLP self: 19 of 3072, tests/test_noise_floor.py)
-MAX_OVER_FRAC = {"base": 0.01, "sharp": 0.01, "white": 0.03, "trained": 0.02}
+# "trained" (a network trained by the build, tests/golden/trained_ckpt.pth): SURVEY 8c's flat per-ray tolerance holds on EVERY ray
+# (measured max 8.2e-5 / 4.5e-4 over 4096 + 1024 rays) -- its smooth coarse pdf has no empty bins, so no sample flips
+MAX_OVER_FRAC = {"base": 0.01, "sharp": 0.01, "white": 0.03, "trained": 0.0}
 
 
 def image_stats(oracle, rgb, dep, ref_rgb, ref_dep):
@@ -337,7 +339,7 @@ def test_family_parity_attributed(amd, oracle, golden, family_sd, family, rays):
     # attribution, every ray, hard -- measured <= 7e-6 / 5.2e-5 on all six scenes, i.e. far inside SURVEY 8c's figures
     assert a_st["rgb_max"] <= 2e-5 and a_st["depth_max"] <= 2e-4, st
     assert st["rays_over_tolerance"] <= MAX_OVER_FRAC[family] * n, st
-    assert st["psnr_db"] >= {"base": 95.0, "sharp": 110.0, "white": 58.0, "trained": 70.0}[family], st    # measured 107.8 / 115.1 / 65.5
+    assert st["psnr_db"] >= {"base": 95.0, "sharp": 110.0, "white": 58.0, "trained": 110.0}[family], st    # measured 107.8 / 115.1 / 65.5 / 118.5
     assert st["rgb_max"] <= HARD_MAX[family][0] and st["depth_max"] <= HARD_MAX[family][1], st
     # the sampler itself (same inputs): moves beyond a bin's rounding amplification are flips; a handful per 65 536
     assert st["sampler_same_inputs"]["samples_moved_gt_1e-3"] <= 0.001 * n * 128, st     # measured <= 22 of 65 536
@@ -753,6 +755,6 @@ def test_family_parity_large_sample(amd, oracle, family_sd, family):
     # attribution, every one of the 4096 rays: measured <= 1.7e-5 / 9.9e-5 (sharp), i.e. 6x / 10x inside SURVEY 8c's figures
     assert a_st["rgb_max"] <= 5e-5 and a_st["depth_max"] <= 5e-4, st
     assert st["rays_over_tolerance"] <= MAX_OVER_FRAC[family] * n, st                  # measured 4 / 2 / 53 of 4096
-    assert st["psnr_db"] >= {"base": 95.0, "sharp": 95.0, "white": 58.0, "trained": 70.0}[family], st    # measured 102.4 / 110.1 / 71.8
-    if family not in ("white", "trained"):
+    assert st["psnr_db"] >= {"base": 95.0, "sharp": 95.0, "white": 58.0, "trained": 105.0}[family], st    # measured 102.4 / 110.1 / 71.8 / 115.8
+    if family != "white":
         assert st["rays_over_tolerance_without_moved_sample"] == 0, st
