@@ -758,3 +758,45 @@ def test_family_parity_large_sample(amd, oracle, family_sd, family):
     assert st["psnr_db"] >= {"base": 95.0, "sharp": 95.0, "white": 58.0, "trained": 105.0}[family], st    # measured 102.4 / 110.1 / 71.8 / 115.8
     if family != "white":
         assert st["rays_over_tolerance_without_moved_sample"] == 0, st
+
+
+def test_render_is_hipgraph_capturable(amd, net, oracle):
+    """The C ABI only enqueues on the caller's stream and never synchronises, so a whole
+    Renderer.render call -- four kernel launches -- can be captured in a hipGraph (torch.cuda.CUDAGraph on ROCm) and replayed
+    on new ray data: bit-identical to the eager call.  This is the launch-bound regime (BASELINE configs[0]-sized batches:
+    1024 rays), where a replay removes the per-launch and Python overhead."""
+    import time
+    ren = amd.Renderer(net)
+    ids = torch.randperm(800 * 800, generator=torch.Generator().manual_seed(5))[:2048]
+    o_all, d_all = oracle.pinhole_rays(800, 800, oracle.camera_pose(300.0), pixel_ids=ids)
+    o_all, d_all = o_all.cuda(), d_all.cuda()
+    static_o, static_d = o_all[:1024].clone(), d_all[:1024].clone()
+    with torch.no_grad():
+        ren.render({"rays_o": static_o[None], "rays_d": static_d[None]})          # warm-up: packs the weights, builds the tables
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ren.render({"rays_o": static_o[None], "rays_d": static_d[None]})      # (allocator warm-up on the capture stream)
+            with torch.cuda.graph(graph, stream=side):
+                g_rgb, g_dep = ren.render({"rays_o": static_o[None], "rays_d": static_d[None]})
+        torch.cuda.current_stream().wait_stream(side)
+        for lo in (0, 1024):                                                       # replay on two different ray sets
+            static_o.copy_(o_all[lo:lo + 1024]); static_d.copy_(d_all[lo:lo + 1024])
+            graph.replay()
+            torch.cuda.synchronize()
+            e_rgb, e_dep = ren.render({"rays_o": o_all[lo:lo + 1024][None], "rays_d": d_all[lo:lo + 1024][None]})
+            assert torch.equal(g_rgb, e_rgb) and torch.equal(g_dep, e_dep)
+        n = 50
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n):
+            graph.replay()
+        torch.cuda.synchronize(); t_graph = (time.perf_counter() - t0) / n
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ren.render({"rays_o": static_o[None], "rays_d": static_d[None]})
+        torch.cuda.synchronize(); t_eager = (time.perf_counter() - t0) / n
+    print(f"1024-ray 64+128 render: eager {t_eager * 1e3:.3f} ms, hipGraph replay {t_graph * 1e3:.3f} ms")
+    parity_record("hipgraph", "render_1024_rays", {"eager_ms": t_eager * 1e3, "replay_ms": t_graph * 1e3})
+    assert t_graph <= 1.2 * t_eager
