@@ -20,7 +20,7 @@
 // nerf_build_flags(), which the Python loader (and any other binder) checks -- so a stray -D can no longer produce a
 // library that passes nerf_abi_version() and computes garbage.
 #define NERF_ANY_TIMING_HACK (NERF_F32_HACK_NOLOAD || NERF_F32_HACK_NOBIAS || NERF_F32_HACK_NORELU || NERF_F32_HACK_NOPE || \
-                              NERF_F32_HACK_NOHEADS || NERF_F32_ASM_OVERRUN || NERF_F32_HACK_NOSAVE || NERF_BWD_HACK_NOMASK || NERF_BWD_HACK_NOGZ || NERF_F16_HACK_NOADV || NERF_F16_HACK_NOBARRIER || NERF_F16_HACK_NOEPI || NERF_F16_HACK_NOBIAS || NERF_F16_HACK_NORELU || NERF_F32X_HACK_NOADV || \
+                              NERF_F32_HACK_NOHEADS || NERF_F32_ASM_OVERRUN || NERF_F32_HACK_NOSAVE || NERF_BWD_HACK_NOMASK || NERF_BWD_HACK_NOGZ || NERF_F16_HACK_NOADV || NERF_F16_HACK_NOBARRIER || NERF_WG_HACK_NOATOMIC || NERF_F16_HACK_NOEPI || NERF_F16_HACK_NOBIAS || NERF_F16_HACK_NORELU || NERF_F32X_HACK_NOADV || \
                               NERF_F32X_HACK_NOPE || NERF_F32X_HACK_NOEPI)
 #if NERF_ANY_TIMING_HACK && !defined(NERF_TIMING_BUILD)
 #error "a NERF_*_HACK_* / NERF_F32_ASM_OVERRUN timing switch is set: such a library computes wrong results; build it with -DNERF_TIMING_BUILD (tools/ab_bench.py does) so that nerf_build_flags() reports it"
