@@ -22,7 +22,8 @@
 #define NERF_ANY_TIMING_HACK (NERF_F32_HACK_NOLOAD || NERF_F32_HACK_NOBIAS || NERF_F32_HACK_NORELU || NERF_F32_HACK_NOPE || \
                               NERF_F32_HACK_NOHEADS || NERF_F32_ASM_OVERRUN || NERF_F32_HACK_NOSAVE || NERF_BWD_HACK_NOMASK || NERF_BWD_HACK_NOGZ || NERF_F16_HACK_NOADV || NERF_F16_HACK_NOBARRIER || NERF_WG_HACK_NOATOMIC || NERF_F16_HACK_NOEPI || NERF_F16_HACK_NOBIAS || NERF_F16_HACK_NORELU || NERF_F32X_HACK_NOADV || \
                               NERF_F32X_HACK_NOPE || NERF_F32X_HACK_NOEPI)
-#if NERF_ANY_TIMING_HACK && !defined(NERF_TIMING_BUILD)
+// (two structural knobs of the SAVE forward also break results when switched off: no rows / no sign bits stored)
+#if (NERF_ANY_TIMING_HACK || NERF_SAVE_TAPS == 0 || NERF_SAVE_BITS == 0) && !defined(NERF_TIMING_BUILD)
 #error "a NERF_*_HACK_* / NERF_F32_ASM_OVERRUN timing switch is set: such a library computes wrong results; build it with -DNERF_TIMING_BUILD (tools/ab_bench.py does) so that nerf_build_flags() reports it"
 #endif
 
@@ -924,7 +925,7 @@ int32_t nerf_build_flags(void) {
 #ifdef NERF_TIMING_BUILD
   f |= NERF_BUILD_TIMING;
 #endif
-#if NERF_ANY_TIMING_HACK
+#if NERF_ANY_TIMING_HACK || NERF_SAVE_TAPS == 0 || NERF_SAVE_BITS == 0
   f |= NERF_BUILD_WRONG_NUMERICS;
 #endif
   return f;
