@@ -80,3 +80,21 @@ def test_inline_asm_weight_stream_has_no_register_hazard():
     # the checker itself: re-creating the prefetch past the stream end (whose registers the compiler reuses) must be caught
     bad = subprocess.run(tool, capture_output=True, text=True, env=dict(os.environ, NERF_CHECK_EXTRA_FLAGS="-DNERF_F32_ASM_OVERRUN=1 -DNERF_TIMING_BUILD"))
     assert bad.returncode == 1 and "touched before its wait" in bad.stdout
+
+
+def test_stray_timing_switch_does_not_build():
+    """A numerics-breaking timing switch (-DNERF_*_HACK_*) must not yield a product library: without -DNERF_TIMING_BUILD
+    the translation unit #errors (round-1 VERDICT "Weak 9"); with it, nerf_build_flags() reports the build and the Python
+    loader refuses it (nerf_replication_amd/_lib.py)."""
+    import shutil
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
+    if hipcc is None:
+        pytest.skip("hipcc not available")
+    src = os.path.join(REPO, "nerf_replication_amd", "csrc", "nerf_kernels.hip")
+    base = [hipcc, "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-fsyntax-only", src]
+    for flag in ("-DNERF_F32_HACK_NOBIAS=1", "-DNERF_F16_HACK_NOADV=1", "-DNERF_SAVE_TAPS=0"):
+        r = subprocess.run(base + [flag], capture_output=True, text=True)
+        assert r.returncode != 0 and "timing switch is set" in r.stderr, (flag, r.stderr[-400:])
+    ok = subprocess.run(base, capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr[-400:]
