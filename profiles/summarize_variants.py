@@ -5,15 +5,19 @@ clock (GRBM_GUI_ACTIVE / 8 XCDs / duration), the MFMA-pipe busy fraction (SQ_VAL
 product (= MFMA-busy cycles per nanosecond, what the time must follow if the kernel is pipe-bound) and the wait fractions."""
 import csv, glob, os, sys
 src, tag = sys.argv[1], sys.argv[2]
+kname = sys.argv[3] if len(sys.argv) > 3 else "nerf_mlp_f16_kernel"          # kernel whose dispatches are summarised
+names = sys.argv[4].split(",") if len(sys.argv) > 4 else None                # variant directories to include (default: all)
 here = os.path.dirname(os.path.abspath(__file__))
 newest = lambda p: max(glob.glob(p), key=os.path.getmtime)
 rows = []
 for d in sorted(glob.glob(os.path.join(src, "var_*"))):
     name = os.path.basename(d)[4:]
-    st = [r for r in csv.DictReader(open(newest(os.path.join(d, "trace", "*", "*_kernel_stats.csv")))) if "nerf_mlp_f16_kernel" in r["Name"]]
+    if names is not None and name not in names:
+        continue
+    st = [r for r in csv.DictReader(open(newest(os.path.join(d, "trace", "*", "*_kernel_stats.csv")))) if kname in r["Name"]]
     c, ns = {}, 0.0
     for r in csv.DictReader(open(newest(os.path.join(d, "pmc", "*", "*_counter_collection.csv")))):
-        if "nerf_mlp_f16_kernel" not in r["Kernel_Name"]:
+        if kname not in r["Kernel_Name"]:
             continue
         c[r["Counter_Name"]] = c.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
