@@ -800,3 +800,30 @@ def test_render_is_hipgraph_capturable(amd, net, oracle):
     print(f"1024-ray 64+128 render: eager {t_eager * 1e3:.3f} ms, hipGraph replay {t_graph * 1e3:.3f} ms")
     parity_record("hipgraph", "render_1024_rays", {"eager_ms": t_eager * 1e3, "replay_ms": t_graph * 1e3})
     assert t_graph <= 1.2 * t_eager
+
+
+@pytest.mark.parametrize("family", ["base", "sharp", "white", "trained"])
+def test_f16_and_f32x_psnr_on_every_family(amd, oracle, golden, family_sd, family):
+    """BASELINE.json's bar for the fp16-activation path is PSNR >= 30 dB against the reference render; the f32x path is held to
+    the fp32 bulk criterion.  Measured on the reference-rendered fixtures of every scene family and recorded."""
+    g = golden(f"render_family_{family}.npz")
+    sd = family_sd(family)
+    out = {}
+    for prec in ("f16", "f32x"):
+        net = amd.Network()
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda().eval()
+        net.precision = prec
+        worst = 1e9
+        for rays in ("seed", "pin"):
+            rgb, dep = _render(amd, net, g[f"{rays}_rays_o"][None], g[f"{rays}_rays_d"][None])
+            st, _ = image_stats(oracle, rgb, dep, g[f"{rays}_rgb"], g[f"{rays}_depth"])
+            out[f"{prec}/{rays}"] = st
+            worst = min(worst, st["psnr_db"])
+        out[f"{prec}/worst_psnr_db"] = worst
+    parity_record("other_precisions_vs_reference", family, out)
+    print(family, {k: (v if not isinstance(v, dict) else (v["psnr_db"], v["rays_over_tolerance"])) for k, v in out.items()})
+    assert out["f16/worst_psnr_db"] >= 30.0, out
+    assert out["f32x/worst_psnr_db"] >= {"base": 95.0, "sharp": 95.0, "white": 55.0, "trained": 105.0}[family], out
+    for rays in ("seed", "pin"):
+        assert out[f"f32x/{rays}"]["rays_over_tolerance"] <= max(1, MAX_OVER_FRAC[family] * 512), out
