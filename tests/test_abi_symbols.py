@@ -74,9 +74,24 @@ def test_inline_asm_weight_stream_has_no_register_hazard():
     if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("hipcc not available")
     tool = [sys.executable, os.path.join(REPO, "tools", "check_asm_stream.py")]
-    r = subprocess.run(tool, capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count(" 0 hazards") == 8 and "no asm loads found" not in r.stdout
+    # csrc/Makefile runs this very check on every build and records the hash of the sources it proved hazard-free next to
+    # the library; when that stamp matches the sources in the tree, the (55 s) positive run is not repeated here
+    import glob
+    import hashlib
+    csrc = os.path.join(REPO, "nerf_replication_amd", "csrc")
+    deps = sorted(set(glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.inc")) +
+                      [os.path.join(REPO, "include", "nerf_mi355x.h"), os.path.join(REPO, "tools", "check_asm_stream.py"),
+                       os.path.join(csrc, "Makefile")]), key=lambda p: os.path.relpath(p, csrc))
+    h = hashlib.sha256()
+    for p in [os.path.join(csrc, "nerf_kernels.hip")] + deps:
+        h.update(open(p, "rb").read())
+    stamp = os.path.join(REPO, "nerf_replication_amd", "libnerf_mi355x.so.checked")
+    proven = os.path.exists(stamp) and open(stamp).read().strip() == h.hexdigest() and \
+        os.path.exists(os.path.join(REPO, "nerf_replication_amd", "libnerf_mi355x.so"))
+    if not proven:
+        r = subprocess.run(tool, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert r.stdout.count(" 0 hazards") == 8 and "no asm loads found" not in r.stdout
     # the checker itself: re-creating the prefetch past the stream end (whose registers the compiler reuses) must be caught
     bad = subprocess.run(tool, capture_output=True, text=True, env=dict(os.environ, NERF_CHECK_EXTRA_FLAGS="-DNERF_F32_ASM_OVERRUN=1 -DNERF_TIMING_BUILD"))
     assert bad.returncode == 1 and "touched before its wait" in bad.stdout
