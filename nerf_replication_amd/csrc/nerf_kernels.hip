@@ -1086,18 +1086,23 @@ int32_t nerf_wgrad(const float* dz, int64_t ldz, int32_t zc0, int32_t n_out, con
     hipLaunchKernelGGL(nerf_wgrad256_f32_kernel, grid, blk, 0, st, a);
   }
   // small layers on the vector-load kernel: (floats per lane, wave split) chosen so that 32*AV*osplit covers n_out
-  // and 32*BV*isplit covers n_in; operands must be aligned to their vector width
-  else if (n_out == 256 && n_in <= 64 && aligned) {                                      // PE -> 256 (layers 0 and 5)
-    a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<4, 1>), vgrid, blk, 0, st, a);
-  } else if (n_out == 128 && n_in == 256 && aligned) {                                   // views_linears.0, feature part
-    a.osplit = 1; a.isplit = 4; hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<4, 2>), vgrid, blk, 0, st, a);
-  } else if (n_out == 128 && n_in <= 32) {                                               // views_linears.0, direction part
-    a.osplit = 4; a.isplit = 1; hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<1, 1>), vgrid, blk, 0, st, a);
-  } else if (n_out <= 32 && n_in == 256 && ldh % 2 == 0 && hc0 % 2 == 0 && (uintptr_t)hin % 8 == 0) {   // alpha_linear
-    a.osplit = 1; a.isplit = 4; hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<1, 2>), vgrid, blk, 0, st, a);
-  } else if (n_out <= 32 && n_in <= 128) {                                               // rgb_linear
-    a.osplit = 1; a.isplit = 4; hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<1, 1>), vgrid, blk, 0, st, a);
-  }
+  // and 32*BV*isplit covers n_in; operands must be aligned to their vector width.  VEC picks the asm-ring form when the
+  // point range splits into whole groups of PF k-steps per workgroup (every training shape does: P is a multiple of 64)
+#define VEC(AV, BV, PF, OS, IS) do { \
+    a.osplit = OS; a.isplit = IS; \
+    if (NERF_WGVEC_ASM && n_points % (2 * PF) == 0 && n_points / (2 * PF) >= 1 && ldz < (1ll << 28) && ldh < (1ll << 28)) { \
+      long long g = n_points / (2 * PF); \
+      if (g > num_cus()) g = num_cus(); \
+      hipLaunchKernelGGL((nerf_wgrad_vec_f32_asm_kernel<AV, BV, PF>), dim3((unsigned)g), blk, 0, st, a); \
+    } else hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<AV, BV>), vgrid, blk, 0, st, a); \
+  } while (0)
+  else if (n_out == 256 && n_in <= 64 && aligned) VEC(4, 1, NERF_WGVEC_PF41, 2, 2);         // PE -> 256 (layers 0 and 5)
+  else if (n_out == 128 && n_in == 256 && aligned) VEC(4, 2, NERF_WGVEC_PF42, 1, 4);        // views_linears.0, feature part
+  else if (n_out == 128 && n_in <= 32) VEC(1, 1, NERF_WGVEC_PF11, 4, 1);                    // views_linears.0, direction part
+  else if (n_out <= 32 && n_in == 256 && ldh % 2 == 0 && hc0 % 2 == 0 && (uintptr_t)hin % 8 == 0)
+    VEC(1, 2, NERF_WGVEC_PF12, 1, 4);                                                       // alpha_linear
+  else if (n_out <= 32 && n_in <= 128) VEC(1, 1, NERF_WGVEC_PF11, 1, 4);                    // rgb_linear
+#undef VEC
   else if (to > 4 && ti > 4) { a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<4, 4>), grid, blk, 0, st, a); }
   else if (to > 4)           { a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<4, 1>), grid, blk, 0, st, a); }
   else if (to > 1 && ti > 4) { a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<2, 4>), grid, blk, 0, st, a); }

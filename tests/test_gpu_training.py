@@ -101,6 +101,44 @@ def test_wgrad_gemm(amd, n_out, n_in, P, aligned):
     assert ((db.cpu().double() - dz[:, zc0:zc0 + n_out].double().sum(0)).abs().max() / scale) <= 2e-5
 
 
+# (ldz, zc0, n_out), (ldh, hc0, n_in), (ldw, wc0), bias: the layouts mlp_backward_impl hands to nerf_wgrad for the small layers
+_SMALL_LAYOUTS = {"rgb_linear": ((4, 0, 3), (128, 0, 128), (128, 0), True),
+                  "alpha_linear": ((4, 3, 1), (256, 0, 256), (256, 0), True),
+                  "views_feature": ((128, 0, 128), (256, 0, 256), (283, 0), True),
+                  "views_dirs": ((128, 0, 128), (32, 0, 27), (283, 256), False),
+                  "pe_skip": ((256, 0, 256), (64, 0, 63), (319, 0), True),
+                  "pe_layer0": ((256, 0, 256), (64, 0, 63), (63, 0), True)}
+
+
+@pytest.mark.parametrize("P", [64, 192 * 64, 64 * 257, 64 * 1031, 100])       # whole 64-point groups: the asm-ring kernels (1 group; even and
+@pytest.mark.parametrize("layer", sorted(_SMALL_LAYOUTS))                      # uneven splits over 256 workgroups); 100: the C++ fallback
+def test_wgrad_small_layers_in_training_layout(amd, layer, P):
+    """The small-layer weight gradients in exactly the row pitches / column offsets of a training step.  Columns that
+    exist in memory but not in the layer (float 63 of a PE row, 27..31 of a direction row, the colour columns next to
+    sigma) hold NaN here: they may be loaded but must not reach any output."""
+    lib, L = amd._lib.load(), amd._lib
+    (ldz, zc0, n_out), (ldh, hc0, n_in), (ldw, wc0), bias = _SMALL_LAYOUTS[layer]
+    gen = torch.Generator().manual_seed(P + n_out)
+    dz = torch.randn(P, ldz, generator=gen)
+    hin = torch.randn(P, ldh, generator=gen)
+    hin_d = hin.clone()
+    hin_d[:, hc0 + n_in:] = float("nan")
+    dw = torch.zeros(n_out, ldw, device="cuda")
+    db = torch.zeros(n_out, device="cuda")
+    dz_d, hin_d = dz.cuda(), hin_d.cuda()
+    L.check(lib.nerf_wgrad(L.ptr(dz_d), ldz, zc0, n_out, L.ptr(hin_d), ldh, hc0, n_in, L.ptr(dw), ldw, wc0,
+                           L.ptr(db) if bias else None, P, L.stream_of(dw.device)))
+    ref = dz[:, zc0:zc0 + n_out].double().T @ hin[:, hc0:hc0 + n_in].double()
+    got = dw.cpu()
+    assert torch.all(got[:, :wc0] == 0) and torch.all(got[:, wc0 + n_in:] == 0)
+    scale = ref.abs().max().clamp_min(1e-6)
+    assert ((got[:, wc0:wc0 + n_in].double() - ref).abs().max() / scale) <= 2e-5
+    if bias:
+        assert ((db.cpu().double() - dz[:, zc0:zc0 + n_out].double().sum(0)).abs().max() / scale) <= 2e-5
+    else:
+        assert torch.all(db == 0)
+
+
 def _grad_ptrs(amd, grads):
     import ctypes
     return (ctypes.c_void_p * 24)(*[g.data_ptr() for g in grads])

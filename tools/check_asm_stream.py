@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Static check of the kernels that fill a register ring with inline-asm loads: nerf_mlp_f32_kernel<*, false> (the
-inference instances) and nerf_wgrad256_f32_asm_kernel.
+inference instances), nerf_wgrad256_f32_asm_kernel and every nerf_wgrad_vec_f32_asm_kernel instance.
 
 The asm `global_load_dwordx4` loads are asynchronous behind the compiler's back: between a load and the asm
 `s_waitcnt vmcnt(N)` that covers it, NO instruction may read or write the destination registers (the compiler could
@@ -28,6 +28,8 @@ KERNELS = ["_Z19nerf_mlp_f32_kernelILb1ELb0ELb0EEv7MlpArgs", "_Z19nerf_mlp_f32_k
            "_Z19nerf_mlp_f32_kernelILb1ELb1ELb1EEv7MlpArgs",
            "_Z23nerf_mlp_bwd_f32_kernelILb0EEv7BwdArgs", "_Z23nerf_mlp_bwd_f32_kernelILb1EEv7BwdArgs",
            "_Z28nerf_wgrad256_f32_asm_kernel10WgradBatch"]
+# every instance of these templates found in the ISA is checked too (their ring depth is part of the mangled name)
+KERNEL_PREFIXES = ["_Z29nerf_wgrad_vec_f32_asm_kernelI"]
 
 
 def vregs(text):
@@ -52,7 +54,7 @@ def check(lines, name):
             ins.append((i, t))
     in_asm = lambda idx: "ASMSTART" in K[ins[idx][0] - 1]
     is_vmem = lambda l: l.startswith(("global_", "buffer_", "scratch_", "flat_"))
-    asm_load = lambda idx: ins[idx][1].startswith("global_load_dwordx4") and "s[" in ins[idx][1] and in_asm(idx)
+    asm_load = lambda idx: re.match(r"global_load_dword(x2|x4)?\b", ins[idx][1]) and "s[" in ins[idx][1] and in_asm(idx)
     loads = [idx for idx in range(len(ins)) if asm_load(idx)]
     hazards = []
 
@@ -103,7 +105,11 @@ def main():
                        stderr=subprocess.DEVNULL)
         lines = open(out).read().split("\n")
     bad = 0
-    for k in KERNELS:
+    found = sorted({m.group(1) for l in lines for m in [re.match(r"^(_Z\w+):", l)] if m and m.group(1).startswith(tuple(KERNEL_PREFIXES))})
+    if not found:
+        print("    (no instance of", KERNEL_PREFIXES, "found)")
+        bad += 1
+    for k in KERNELS + found:
         n, hz = check(lines, k)
         print(f"{k}: {n} asm loads, {len(hz)} hazards")
         for kind, ld, use in hz[:10]:
