@@ -33,6 +33,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 FLOP_PER_POINT = 1186816                 # 2 x 593 408 MAC, unpadded
+FLOP_DENSITY_SKIPPED = 204288            # feature_linear + views_linears.0 + rgb_linear: not evaluated by a density-only pass
 POINTS_PER_RAY = 64 + 192
 PEAK_F32_MFMA = 157.3e12                 # MI355X_MICROARCH.md chip table
 PEAK_F16_MFMA = 2.5e15                   # dense fp16/bf16 MFMA, same table
@@ -71,19 +72,23 @@ def time_stages(pkg, net, ren, o, d, steps, prec=0):
     raw_f = torch.empty(n, 192, 4, device=dev)
     rgb, dep = torch.empty(n, 3, device=dev), torch.empty(n, device=dev)
     st = L.stream_of(dev)
-    names = ["mlp_coarse", "sample_fine", "mlp_fine", "composite"]
+    # mlp_coarse is the launch nerf_render_forward makes (density-only: the reference reads nothing but sigma of the coarse
+    # output when N_importance > 0, volume_renderer.py:335); mlp_coarse_full_network times the full coarse network beside it
+    names = ["mlp_coarse_full_network", "mlp_coarse", "sample_fine", "mlp_fine", "composite"]
     acc = dict.fromkeys(names, 0.0)
     for _ in range(steps):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
         ev[0].record()
         L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t_c), 0, n, 64, pk_c.data_ptr(), L.ptr(raw_c), prec, st))
         ev[1].record()
-        L.check(lib.nerf_sample_fine(L.ptr(raw_c), L.ptr(t_c), L.ptr(u), n, L.ptr(t_sorted), None, None, 0.0, 0.0, st))
+        L.check(lib.nerf_mlp_forward_rays_density(L.ptr(o), L.ptr(d), L.ptr(t_c), 0, n, 64, pk_c.data_ptr(), L.ptr(raw_c), prec, st))
         ev[2].record()
-        L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t_sorted), 192, n, 192, pk_f.data_ptr(), L.ptr(raw_f), prec, st))
+        L.check(lib.nerf_sample_fine(L.ptr(raw_c), L.ptr(t_c), L.ptr(u), n, L.ptr(t_sorted), None, None, 0.0, 0.0, st))
         ev[3].record()
-        L.check(lib.nerf_composite(L.ptr(raw_f), L.ptr(t_sorted), 192, n, 192, 1, L.ptr(rgb), L.ptr(dep), None, st))
+        L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t_sorted), 192, n, 192, pk_f.data_ptr(), L.ptr(raw_f), prec, st))
         ev[4].record()
+        L.check(lib.nerf_composite(L.ptr(raw_f), L.ptr(t_sorted), 192, n, 192, 1, L.ptr(rgb), L.ptr(dep), None, st))
+        ev[5].record()
         torch.cuda.synchronize()
         for i, k in enumerate(names):
             acc[k] += ev[i].elapsed_time(ev[i + 1])
@@ -379,7 +384,13 @@ def main():
     # dominant-kernel roofline on this rank's shard (HIP events on the launch stream)
     stages = time_stages(pkg, net, ren, o, d, max(1, min(args.steps, 3)), prec)
     mlp_ms_per_launch = (stages["mlp_coarse"] + stages["mlp_fine"]) / 2.0
-    flop_per_launch = (hi - lo) * POINTS_PER_RAY * FLOP_PER_POINT / 2.0
+    # FLOP actually executed: the fp32 coarse launch stops after the sigma head (feature_linear 256x256, views_linears.0
+    # 283x128 and rgb_linear 128x3 = 204 288 FLOP per point are never read by the reference's hierarchical render and are
+    # not evaluated); the fp16 / split-fp16 kernels run the coarse network in full
+    coarse_flop_per_point = FLOP_PER_POINT - (FLOP_DENSITY_SKIPPED if prec == 0 else 0)
+    flop_frame_executed = (hi - lo) * (64 * coarse_flop_per_point + 192 * FLOP_PER_POINT)
+    flop_frame_reference = (hi - lo) * POINTS_PER_RAY * FLOP_PER_POINT
+    flop_per_launch = flop_frame_executed / 2.0
     achieved = flop_per_launch / (mlp_ms_per_launch * 1e-3) / 1e12
     traffic, traffic_src = None, None
     try:      # HBM bytes per launch come from separate rocprofv3 --pmc passes (cannot be read in-process);
@@ -391,7 +402,12 @@ def main():
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
                 "frac": round(achieved / (peak / 1e12), 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": f"nerf_mlp_{args.precision}_kernel", "avg_launch_ms": round(mlp_ms_per_launch, 3),
-                "stage_ms": {k: round(v, 3) for k, v in stages.items()}}
+                "flop_per_frame_executed": flop_frame_executed, "flop_per_frame_reference_algorithm": flop_frame_reference,
+                "stage_ms": {k: round(v, 3) for k, v in stages.items()},
+                # the same frame with the coarse network evaluated in full (its colour computed and dropped, as the reference
+                # does): derived from the measured step time and the two coarse launches timed side by side above
+                "rays_per_s_if_coarse_colour_were_computed":
+                    round(n / ((ms_per_step + stages["mlp_coarse_full_network"] - stages["mlp_coarse"]) * 1e-3), 1)}
 
     out = None
     if rank == 0:
@@ -404,6 +420,10 @@ def main():
                                       "hierarchical samples, 8+1-layer W=256 NeRF x2, seeded synthetic weights "
                                       "(latest.pth unavailable offline); BASELINE.json "
                                       + ("configs[1]" if H == 800 else "configs[4] frame size" if H == 1600 else "custom frame size"),
+                          "coarse_pass": ("density-only fp32 launch: sigma is the only coarse output the reference reads when "
+                                          "N_importance > 0 (volume_renderer.py:335), rgb/depth are bit-identical to running "
+                                          "the full coarse network; see roofline.rays_per_s_if_coarse_colour_were_computed"
+                                          if prec == 0 else "full coarse network (only the fp32 kernel has a density-only instance)"),
                           "rays_per_step": n, "parallelism": f"ray-tile shard x{world} (each rank generates and renders only "
                                                              "its tile) + 1 all_gather",
                           **({"fast_sampling": "ESS/ERT masks, weights_threshold %.2f; the roofline block times the UNMASKED "

@@ -555,49 +555,79 @@ void nerf_composite_bwd_kernel(const float* __restrict__ raw, const float* __res
   const float gr = g_rgb[ray * 3 + 0], gg = g_rgb[ray * 3 + 1], gb = g_rgb[ray * 3 + 2];
   const float gd = g_depth ? g_depth[ray] : 0.0f;
   const float wb = white_bkgd ? 1.0f : 0.0f;
+  // One thread per ray means one exposed HBM latency per sequential step unless the loads are issued ahead of the scan:
+  // both sweeps fetch kCbBatch steps (raw quads + depths, clamped to the row) into registers first, then scan them.
+  constexpr int kCbBatch = 16;
   {
     float T = 1.0f;
-    for (int k = 0; k < S; ++k) {
-      Tk_row[k] = T;
-      const float sig = fmaxf(r4[k].w, 0.0f);
-      const float delta = (k < S - 1) ? __fsub_rn(t[k + 1], t[k]) : 1e10f;
-      const float alpha = alpha_of(sig, delta);
-      T = __fmul_rn(T, fminf(fmaxf(__fsub_rn(1.0f, alpha), 1e-10f), 1.0f));
+    for (int k0 = 0; k0 < S; k0 += kCbBatch) {
+      float sg[kCbBatch], tt[kCbBatch + 1];
+#pragma unroll
+      for (int j = 0; j < kCbBatch; ++j) sg[j] = r4[min(k0 + j, S - 1)].w;
+#pragma unroll
+      for (int j = 0; j <= kCbBatch; ++j) tt[j] = t[min(k0 + j, S - 1)];
+#pragma unroll
+      for (int j = 0; j < kCbBatch; ++j) {
+        const int k = k0 + j;
+        if (k < S) {
+          Tk_row[k] = T;
+          const float sig = fmaxf(sg[j], 0.0f);
+          const float delta = (k < S - 1) ? __fsub_rn(tt[j + 1], tt[j]) : 1e10f;
+          const float alpha = alpha_of(sig, delta);
+          T = __fmul_rn(T, fminf(fmaxf(__fsub_rn(1.0f, alpha), 1e-10f), 1.0f));
+        }
+      }
     }
   }
   // reverse: suf = sum_{m>k} g_T_m T_m  (g_T_m = g_w_m a_m);  g_q_k = suf / q_k
   float suf = 0.0f;
-  for (int k = S - 1; k >= 0; --k) {
-    const f32x4 v = r4[k];
-    const float sig = fmaxf(v.w, 0.0f);
-    const float tk = t[k];
-    const float delta = (k < S - 1) ? __fsub_rn(t[k + 1], tk) : 1e10f;
-    const float e = expf(__fmul_rn(-sig, delta));
-    const float alpha = __fsub_rn(1.0f, e);
-    const float om = __fsub_rn(1.0f, alpha);
-    const float q = fminf(fmaxf(om, 1e-10f), 1.0f);
-    const float Tk = Tk_row[k];
-    const float cr = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v.x)));
-    const float cg = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v.y)));
-    const float cb = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v.z)));
-    const float g_w = gr * (cr - wb) + gg * (cg - wb) + gb * (cb - wb) + gd * tk;
-    const float w = Tk * alpha;
-    float g_alpha = g_w * Tk;
-    if (om >= 1e-10f && om <= 1.0f) g_alpha -= suf / q;      // clamp passes the gradient inside its range
-    suf += g_w * alpha * Tk;                                 // g_T_k T_k joins the suffix for smaller k
-    const float g_sig = g_alpha * delta * e;
-    const float g_delta = (k < S - 1) ? g_alpha * sig * e : 0.0f;
-    f32x4 go;
-    go.x = gr * w * cr * (1.0f - cr);
-    go.y = gg * w * cg * (1.0f - cg);
-    go.z = gb * w * cb * (1.0f - cb);
-    go.w = v.w > 0.0f ? g_sig : 0.0f;
-    g4[k] = go;
-    if (gt) {
-      gt[k] = gd * w - g_delta;                              // delta_k = t_{k+1} - t_k
-      if (k < S - 1) gt[k + 1] += g_delta;
+  float gt_pending = 0.0f;                                   // gd w_{k+1} - g_delta_{k+1}: g_t[k + 1] is written once, complete,
+                                                             // when step k supplies + g_delta_k (no read-modify-write in memory)
+  for (int k1 = (S + kCbBatch - 1) / kCbBatch * kCbBatch; k1 > 0; k1 -= kCbBatch) {
+    const int k0 = k1 - kCbBatch;
+    f32x4 vv[kCbBatch];
+    float tt[kCbBatch + 1];
+#pragma unroll
+    for (int j = 0; j < kCbBatch; ++j) vv[j] = r4[min(k0 + j, S - 1)];
+#pragma unroll
+    for (int j = 0; j <= kCbBatch; ++j) tt[j] = t[min(k0 + j, S - 1)];
+#pragma unroll
+    for (int j = kCbBatch - 1; j >= 0; --j) {
+      const int k = k0 + j;
+      if (k >= S) continue;
+      const f32x4 v = vv[j];
+      const float sig = fmaxf(v.w, 0.0f);
+      const float tk = tt[j];
+      const float delta = (k < S - 1) ? __fsub_rn(tt[j + 1], tk) : 1e10f;
+      const float e = expf(__fmul_rn(-sig, delta));
+      const float alpha = __fsub_rn(1.0f, e);
+      const float om = __fsub_rn(1.0f, alpha);
+      const float q = fminf(fmaxf(om, 1e-10f), 1.0f);
+      const float Tk = Tk_row[k];
+      const float cr = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v.x)));
+      const float cg = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v.y)));
+      const float cb = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v.z)));
+      const float g_w = gr * (cr - wb) + gg * (cg - wb) + gb * (cb - wb) + gd * tk;
+      const float w = Tk * alpha;
+      float g_alpha = g_w * Tk;
+      if (om >= 1e-10f && om <= 1.0f) g_alpha -= suf / q;      // clamp passes the gradient inside its range
+      suf += g_w * alpha * Tk;                                 // g_T_k T_k joins the suffix for smaller k
+      const float g_sig = g_alpha * delta * e;
+      const float g_delta = (k < S - 1) ? g_alpha * sig * e : 0.0f;
+      f32x4 go;
+      go.x = gr * w * cr * (1.0f - cr);
+      go.y = gg * w * cg * (1.0f - cg);
+      go.z = gb * w * cb * (1.0f - cb);
+      go.w = v.w > 0.0f ? g_sig : 0.0f;
+      g4[k] = go;
+      if (gt) {
+        // delta_k = t_{k+1} - t_k:  g_t[k] = gd w_k - g_delta_k (+ g_delta_{k-1}, known one step later)
+        if (k < S - 1) gt[k + 1] = gt_pending + g_delta;
+        gt_pending = gd * w - g_delta;
+      }
     }
   }
+  if (gt) gt[0] = gt_pending;
 }
 
 // Backward of hierarchical sampling (volume_renderer.py:126-154, :247-264 under autograd): gradient of the
@@ -906,7 +936,9 @@ int launch_mlp(const MlpArgs& a, bool ray_mode, int precision, hipStream_t st) {
   if (blocks > num_cus()) blocks = num_cus();          // 512 registers per wave: exactly one workgroup per CU
 #endif
   if (blocks > 0x7fffffffLL) return fail(NERF_ERR_INVALID_ARG, "%s", "too many points for one launch");
-  if (ray_mode) hipLaunchKernelGGL(nerf_mlp_f32_kernel<true>, dim3((unsigned)blocks), dim3(64 * NERF_F32_WG_WAVES), 0, st, a);
+  // density_only (ray mode, fp32): the instance that stops after the sigma head; the fp16 / split-fp16 kernels run in full
+  if (ray_mode && a.density_only) hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, false, true>), dim3((unsigned)blocks), dim3(64 * NERF_F32_WG_WAVES), 0, st, a);
+  else if (ray_mode) hipLaunchKernelGGL(nerf_mlp_f32_kernel<true>, dim3((unsigned)blocks), dim3(64 * NERF_F32_WG_WAVES), 0, st, a);
   else hipLaunchKernelGGL(nerf_mlp_f32_kernel<false>, dim3((unsigned)blocks), dim3(64 * NERF_F32_WG_WAVES), 0, st, a);
   return check_launch("nerf_mlp_f32_kernel");
 }
@@ -989,6 +1021,19 @@ int32_t nerf_mlp_forward_rays(const float* rays_o, const float* rays_d, const fl
   MlpArgs a{};
   a.rays_o = rays_o; a.rays_d = rays_d; a.tvals = tvals; a.t_ray_stride = t_ray_stride;
   a.n_points = n_rays * n_samples; a.n_samples = n_samples; a.packed = (const float*)packed; a.raw = raw;
+  return launch_mlp(a, true, precision, (hipStream_t)stream);
+}
+
+int32_t nerf_mlp_forward_rays_density(const float* rays_o, const float* rays_d, const float* tvals,
+                                      int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
+                                      const void* packed, float* raw, int32_t precision, void* stream) {
+  if (n_rays < 0 || n_samples <= 0 || t_ray_stride < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_rays_density: bad size");
+  if (n_rays == 0) return NERF_OK;
+  if (!rays_o || !rays_d || !tvals || !packed || !raw) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_rays_density: null argument");
+  MlpArgs a{};
+  a.rays_o = rays_o; a.rays_d = rays_d; a.tvals = tvals; a.t_ray_stride = t_ray_stride;
+  a.n_points = n_rays * n_samples; a.n_samples = n_samples; a.packed = (const float*)packed; a.raw = raw;
+  a.density_only = 1;
   return launch_mlp(a, true, precision, (hipStream_t)stream);
 }
 
@@ -1439,7 +1484,11 @@ int32_t nerf_render_forward(const float* rays_o, const float* rays_d, int64_t n_
                                             "(n_rays * 192 point ids must fit in int32): split the frame");
   char* ws = (char*)workspace;
   float* raw_c = (float*)ws;
-  int rc = nerf_mlp_forward_rays(rays_o, rays_d, t_coarse, 0, n_rays, NERF_N_SAMPLES, packed_coarse, raw_c, precision, stream);
+  // hierarchical render: the coarse network only places the fine samples -- nothing but its sigma is read
+  // (volume_renderer.py:335; the returned rgb/depth come from the fine outputs, :414-437), so the coarse pass stops after
+  // the sigma head.  With n_importance == 0 the coarse outputs ARE the frame and the full network runs.
+  int rc = n_importance ? nerf_mlp_forward_rays_density(rays_o, rays_d, t_coarse, 0, n_rays, NERF_N_SAMPLES, packed_coarse, raw_c, precision, stream)
+                        : nerf_mlp_forward_rays(rays_o, rays_d, t_coarse, 0, n_rays, NERF_N_SAMPLES, packed_coarse, raw_c, precision, stream);
   if (rc) return rc;
   if (n_importance == 0)
     return nerf_composite(raw_c, t_coarse, 0, n_rays, NERF_N_SAMPLES, white_bkgd, rgb, depth, nullptr, stream);

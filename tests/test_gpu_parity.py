@@ -179,6 +179,37 @@ def test_mlp_rays_mode_points_bit_exact(amd, net, golden):
     assert _chan_err(raw_rays, g["raw_fine"]) <= RAW_RTOL
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16", "f32x"])
+@pytest.mark.parametrize("n_rays,S,stride", [(256, 192, 192), (1000, 64, 0), (3, 64, 0)])     # per-ray depths; the shared coarse table; a ragged tile
+def test_density_only_forward_is_the_full_forwards_sigma(amd, synthetic_sd, golden, precision, n_rays, S, stride):
+    """nerf_mlp_forward_rays_density (the coarse pass of nerf_render_forward when N_importance > 0: the reference reads only
+    outputs[..., 3] of the coarse network, volume_renderer.py:335) must write BIT FOR BIT the sigma nerf_mlp_forward_rays
+    writes; fp32 zeroes the colour columns (it stops after the sigma head), the other precisions run in full."""
+    lib, L = amd._lib.load(), amd._lib
+    net = amd.Network(); net.load_state_dict(synthetic_sd); net = net.cuda().eval(); net.precision = precision
+    prec = L.PRECISIONS[precision]
+    gen = torch.Generator().manual_seed(n_rays)
+    d = torch.randn(n_rays, 3, generator=gen).cuda()
+    o = (torch.randn(n_rays, 3, generator=gen) * 0.1 + torch.tensor([0.0, 0.0, 4.0])).cuda()
+    if stride:
+        t = torch.sort(torch.rand(n_rays, S, generator=gen) * 4 + 2, dim=-1).values.cuda().contiguous()
+    else:
+        t = torch.linspace(2.0, 6.0, S).cuda()
+    full = torch.full((n_rays, S, 4), float("nan"), device="cuda")
+    dens = torch.full((n_rays, S, 4), float("nan"), device="cuda")
+    st = L.stream_of(o.device)
+    pk = net.packed("").data_ptr()
+    L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t), stride, n_rays, S, pk, L.ptr(full), prec, st))
+    L.check(lib.nerf_mlp_forward_rays_density(L.ptr(o), L.ptr(d), L.ptr(t), stride, n_rays, S, pk, L.ptr(dens), prec, st))
+    torch.cuda.synchronize()
+    assert torch.isfinite(full).all() and torch.isfinite(dens).all()
+    assert torch.equal(dens[..., 3], full[..., 3])
+    if precision == "f32":
+        assert torch.all(dens[..., :3] == 0)
+    else:
+        assert torch.equal(dens, full)
+
+
 def test_fine_sampling_stage(amd, golden):
     g = golden("sampling.npz")
     lib, L = amd._lib.load(), amd._lib
