@@ -60,7 +60,7 @@ def load_weights():
     return ck["net"]
 
 
-def time_stages(pkg, net, ren, o, d, steps, prec=0):
+def time_stages(pkg, net, ren, o, d, steps, prec=0, full_coarse=False):
     """HIP-event time of each kernel of the render path, launched through the C ABI on torch's
     current stream (the stream the events are recorded on)."""
     L, lib = pkg._lib, pkg._lib.load()
@@ -73,13 +73,15 @@ def time_stages(pkg, net, ren, o, d, steps, prec=0):
     rgb, dep = torch.empty(n, 3, device=dev), torch.empty(n, device=dev)
     st = L.stream_of(dev)
     # mlp_coarse is the launch nerf_render_forward makes (density-only: the reference reads nothing but sigma of the coarse
-    # output when N_importance > 0, volume_renderer.py:335); mlp_coarse_full_network times the full coarse network beside it
+    # output when N_importance > 0, volume_renderer.py:335); with --compare-full-coarse, mlp_coarse_full_network times the full
+    # coarse network beside it (off by default: its launches would mix into the fine launches' row of `rocprofv3 --stats`)
     names = ["mlp_coarse_full_network", "mlp_coarse", "sample_fine", "mlp_fine", "composite"]
     acc = dict.fromkeys(names, 0.0)
     for _ in range(steps):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
         ev[0].record()
-        L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t_c), 0, n, 64, pk_c.data_ptr(), L.ptr(raw_c), prec, st))
+        if full_coarse:
+            L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t_c), 0, n, 64, pk_c.data_ptr(), L.ptr(raw_c), prec, st))
         ev[1].record()
         L.check(lib.nerf_mlp_forward_rays_density(L.ptr(o), L.ptr(d), L.ptr(t_c), 0, n, 64, pk_c.data_ptr(), L.ptr(raw_c), prec, st))
         ev[2].record()
@@ -92,6 +94,8 @@ def time_stages(pkg, net, ren, o, d, steps, prec=0):
         torch.cuda.synchronize()
         for i, k in enumerate(names):
             acc[k] += ev[i].elapsed_time(ev[i + 1])
+    if not full_coarse:
+        del acc["mlp_coarse_full_network"]
     return {k: v / steps for k, v in acc.items()}
 
 
@@ -241,12 +245,15 @@ def run_config5(pkg, sd, dev, world, rank, steps=2):
         elapsed = tt.item()
     finite = bool(torch.isfinite(rgb).all().item() and torch.isfinite(dep).all().item())
     rays_per_s = n * steps / elapsed
-    return {"workload": "1600x1600 frame = 2560000 rays, 64+128, fp16 activations + fp32 accumulate (nerf_mlp_f16_kernel)",
+    # executed FLOP per ray: the coarse launch is density-only (see the headline's config.coarse_pass)
+    flop_per_ray = 64 * (FLOP_PER_POINT - FLOP_DENSITY_SKIPPED) + 192 * FLOP_PER_POINT
+    return {"workload": "1600x1600 frame = 2560000 rays, 64+128 (coarse pass density-only), fp16 activations + fp32 accumulate (nerf_mlp_f16_kernel)",
             "rays_per_s": round(rays_per_s, 1), "ms_per_frame": round(elapsed / steps * 1e3, 2), "steps": steps, "warmup": 1,
             "n_gpus": world, "finite": finite,
-            "roofline": {"bound": "mfma", "achieved": round(rays_per_s * POINTS_PER_RAY * FLOP_PER_POINT / 1e12, 1),
+            "roofline": {"bound": "mfma", "achieved": round(rays_per_s * flop_per_ray / 1e12, 1),
                          "peak": PEAK_F16_MFMA * world / 1e12, "unit": "TFLOP/s",
-                         "frac": round(rays_per_s * POINTS_PER_RAY * FLOP_PER_POINT / (PEAK_F16_MFMA * world), 4)}}
+                         "frac": round(rays_per_s * flop_per_ray / (PEAK_F16_MFMA * world), 4),
+                         "flop_per_ray_executed": flop_per_ray, "flop_per_ray_reference_algorithm": POINTS_PER_RAY * FLOP_PER_POINT}}
 
 
 def cpu_baseline_config1(sd):
@@ -285,6 +292,9 @@ def main():
                     help="the reference's optional ESS/ERT masked fine pass (volume_renderer.py:132-244, off in lego.yaml): "
                          "fine samples the coarse pass marks empty or occluded skip the MLP; a different image, reported "
                          "as its own metric")
+    ap.add_argument("--compare-full-coarse", action="store_true",
+                    help="also time the FULL coarse network (colour branch included) beside the density-only coarse launch the "
+                         "render makes, and report the frame rate the headline would have with it (profiles/r02_full_coarse_compare.json)")
     ap.add_argument("--no-extras", dest="extras", action="store_false",
                     help="skip the training (configs[2]) and 1600x1600 f16 (configs[4]) blocks that follow the headline")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32x"],
@@ -382,12 +392,12 @@ def main():
         print(f"[bench] {args.steps} steps: {ms_per_step:.1f} ms/step, {value:.0f} rays/s", file=sys.stderr, flush=True)
 
     # dominant-kernel roofline on this rank's shard (HIP events on the launch stream)
-    stages = time_stages(pkg, net, ren, o, d, max(1, min(args.steps, 3)), prec)
+    stages = time_stages(pkg, net, ren, o, d, max(1, min(args.steps, 3)), prec, full_coarse=args.compare_full_coarse)
     mlp_ms_per_launch = (stages["mlp_coarse"] + stages["mlp_fine"]) / 2.0
-    # FLOP actually executed: the fp32 coarse launch stops after the sigma head (feature_linear 256x256, views_linears.0
+    # FLOP actually executed: the coarse launch stops after the sigma head (feature_linear 256x256, views_linears.0
     # 283x128 and rgb_linear 128x3 = 204 288 FLOP per point are never read by the reference's hierarchical render and are
-    # not evaluated); the fp16 / split-fp16 kernels run the coarse network in full
-    coarse_flop_per_point = FLOP_PER_POINT - (FLOP_DENSITY_SKIPPED if prec == 0 else 0)
+    # not evaluated)
+    coarse_flop_per_point = FLOP_PER_POINT - FLOP_DENSITY_SKIPPED
     flop_frame_executed = (hi - lo) * (64 * coarse_flop_per_point + 192 * FLOP_PER_POINT)
     flop_frame_reference = (hi - lo) * POINTS_PER_RAY * FLOP_PER_POINT
     flop_per_launch = flop_frame_executed / 2.0
@@ -403,11 +413,12 @@ def main():
                 "frac": round(achieved / (peak / 1e12), 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": f"nerf_mlp_{args.precision}_kernel", "avg_launch_ms": round(mlp_ms_per_launch, 3),
                 "flop_per_frame_executed": flop_frame_executed, "flop_per_frame_reference_algorithm": flop_frame_reference,
-                "stage_ms": {k: round(v, 3) for k, v in stages.items()},
-                # the same frame with the coarse network evaluated in full (its colour computed and dropped, as the reference
-                # does): derived from the measured step time and the two coarse launches timed side by side above
-                "rays_per_s_if_coarse_colour_were_computed":
-                    round(n / ((ms_per_step + stages["mlp_coarse_full_network"] - stages["mlp_coarse"]) * 1e-3), 1)}
+                "stage_ms": {k: round(v, 3) for k, v in stages.items()}}
+    if args.compare_full_coarse:
+        # the same frame with the coarse network evaluated in full (its colour computed and dropped, as the reference
+        # does): derived from the measured step time and the two coarse launches timed side by side
+        roofline["rays_per_s_if_coarse_colour_were_computed"] = round(
+            n / ((ms_per_step + stages["mlp_coarse_full_network"] - stages["mlp_coarse"]) * 1e-3), 1)
 
     out = None
     if rank == 0:
@@ -420,10 +431,10 @@ def main():
                                       "hierarchical samples, 8+1-layer W=256 NeRF x2, seeded synthetic weights "
                                       "(latest.pth unavailable offline); BASELINE.json "
                                       + ("configs[1]" if H == 800 else "configs[4] frame size" if H == 1600 else "custom frame size"),
-                          "coarse_pass": ("density-only fp32 launch: sigma is the only coarse output the reference reads when "
+                          "coarse_pass": ("density-only launch: sigma is the only coarse output the reference reads when "
                                           "N_importance > 0 (volume_renderer.py:335), rgb/depth are bit-identical to running "
-                                          "the full coarse network; see roofline.rays_per_s_if_coarse_colour_were_computed"
-                                          if prec == 0 else "full coarse network (only the fp32 kernel has a density-only instance)"),
+                                          "the full coarse network (--compare-full-coarse times that beside it: profiles/r02_full_coarse_compare.json)"
+                                          ),
                           "rays_per_step": n, "parallelism": f"ray-tile shard x{world} (each rank generates and renders only "
                                                              "its tile) + 1 all_gather",
                           **({"fast_sampling": "ESS/ERT masks, weights_threshold %.2f; the roofline block times the UNMASKED "

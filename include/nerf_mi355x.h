@@ -85,9 +85,9 @@ int32_t nerf_mlp_forward_rays(const float* rays_o, const float* rays_d, const fl
 /* Density-only form of nerf_mlp_forward_rays: raw[..., 3] = sigma, bit for bit the value nerf_mlp_forward_rays writes there.
  * In a hierarchical render (N_importance > 0) the reference reads nothing else of the coarse network's output
  * (volume_renderer.py:335 `density_coarse = outputs[...,3]`; rgb and depth are composited from the fine outputs, :414-437), so
- * nerf_render_forward runs its coarse pass through this entry.  NERF_PREC_F32: the network stops after the sigma head
- * (feature_linear, views_linears.0 and rgb_linear are not evaluated: 982 528 instead of 1 186 816 FLOP per point) and the rgb
- * columns of `raw` are written as 0; NERF_PREC_F16 / NERF_PREC_F32X: identical to nerf_mlp_forward_rays (rgb columns included). */
+ * nerf_render_forward runs its coarse pass through this entry.  The network stops after the sigma head (feature_linear,
+ * views_linears.0 and rgb_linear are not evaluated: 982 528 instead of 1 186 816 FLOP per point) and the rgb columns of `raw`
+ * are written as 0, in every precision. */
 int32_t nerf_mlp_forward_rays_density(const float* rays_o, const float* rays_d, const float* tvals,
                                       int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
                                       const void* packed, float* raw, int32_t precision, void* stream);

@@ -915,14 +915,16 @@ int launch_mlp(const MlpArgs& a, bool ray_mode, int precision, hipStream_t st) {
   if (precision == NERF_PREC_F32X) {       // persistent workgroups of 4 waves, one per CU
     const long long n_tiles = (a.n_points + kXTilePts - 1) / kXTilePts;
     const unsigned blocks = (unsigned)(n_tiles < num_cus() ? n_tiles : num_cus());
-    if (ray_mode) hipLaunchKernelGGL(nerf_mlp_f32x_kernel<true>, dim3(blocks), dim3(kXThreads), 0, st, a);
+    if (ray_mode && a.density_only) hipLaunchKernelGGL((nerf_mlp_f32x_kernel<true, false, true>), dim3(blocks), dim3(kXThreads), 0, st, a);
+    else if (ray_mode) hipLaunchKernelGGL(nerf_mlp_f32x_kernel<true>, dim3(blocks), dim3(kXThreads), 0, st, a);
     else hipLaunchKernelGGL(nerf_mlp_f32x_kernel<false>, dim3(blocks), dim3(kXThreads), 0, st, a);
     return check_launch("nerf_mlp_f32x_kernel");
   }
   if (precision == NERF_PREC_F16) {        // persistent workgroups, one per CU (147 KB of LDS each)
     const long long n_tiles = (a.n_points + kF16TilePts - 1) / kF16TilePts;
     const unsigned blocks = (unsigned)(n_tiles < num_cus() ? n_tiles : num_cus());
-    if (ray_mode) hipLaunchKernelGGL(nerf_mlp_f16_kernel<true>, dim3(blocks), dim3(kF16Threads), 0, st, a);
+    if (ray_mode && a.density_only) hipLaunchKernelGGL((nerf_mlp_f16_kernel<true, true>), dim3(blocks), dim3(kF16Threads), 0, st, a);
+    else if (ray_mode) hipLaunchKernelGGL(nerf_mlp_f16_kernel<true>, dim3(blocks), dim3(kF16Threads), 0, st, a);
     else hipLaunchKernelGGL(nerf_mlp_f16_kernel<false>, dim3(blocks), dim3(kF16Threads), 0, st, a);
     return check_launch("nerf_mlp_f16_kernel");
   }
@@ -936,7 +938,7 @@ int launch_mlp(const MlpArgs& a, bool ray_mode, int precision, hipStream_t st) {
   if (blocks > num_cus()) blocks = num_cus();          // 512 registers per wave: exactly one workgroup per CU
 #endif
   if (blocks > 0x7fffffffLL) return fail(NERF_ERR_INVALID_ARG, "%s", "too many points for one launch");
-  // density_only (ray mode, fp32): the instance that stops after the sigma head; the fp16 / split-fp16 kernels run in full
+  // density_only (ray mode): every precision has an instance that stops after the sigma head
   if (ray_mode && a.density_only) hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, false, true>), dim3((unsigned)blocks), dim3(64 * NERF_F32_WG_WAVES), 0, st, a);
   else if (ray_mode) hipLaunchKernelGGL(nerf_mlp_f32_kernel<true>, dim3((unsigned)blocks), dim3(64 * NERF_F32_WG_WAVES), 0, st, a);
   else hipLaunchKernelGGL(nerf_mlp_f32_kernel<false>, dim3((unsigned)blocks), dim3(64 * NERF_F32_WG_WAVES), 0, st, a);

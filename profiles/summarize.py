@@ -131,7 +131,9 @@ if kname:
         "kernel": kname, "workload": "800x800, 64+128, 1 GPU", "launches_per_frame": 2,
         "fetch_bytes_per_launch": mean("FETCH_SIZE") * 1024 * 2, "write_bytes_per_launch": mean("WRITE_SIZE") * 1024,
         "traffic_bytes_per_launch": mean("FETCH_SIZE") * 1024 * 2 + mean("WRITE_SIZE") * 1024,
-        "rocprof_avg_launch_ms": float(stats[0]["AverageNs"]) / 1e6 if stats else None,
+        # average over every launch of the kernel (both template instances: the density-only coarse launch and the fine launch)
+        "rocprof_avg_launch_ms": (sum(float(r["TotalDurationNs"]) for r in stats) / sum(int(r["Calls"]) for r in stats) / 1e6) if stats else None,
+        "rocprof_avg_ms_by_instance": {kname_of(r["Name"]): float(r["AverageNs"]) / 1e6 for r in stats},
         "mfma_busy_frac": sum(per["SQ_VALU_MFMA_BUSY_CYCLES"]) / (sum(per["GRBM_GUI_ACTIVE"]) * 128.0),
         "clock_ghz": clk_num / clk_den / 8.0,          # GRBM_GUI_ACTIVE is summed over the 8 XCDs
         "source": f"profiles/{tag}_pmc.csv, profiles/{tag}_kernel_stats.csv (profiles/collect.sh: rocprofv3 --pmc in separate "
