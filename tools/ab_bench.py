@@ -28,6 +28,13 @@ def build(name, extra):
     subprocess.run(cmd, shell=True, check=True)
     with open(out + ".flags", "w") as f:          # what this binary was built with: a stale or flag-less rebuild cannot pose as it
         f.write(extra.strip())
+    if os.environ.get("AB_NO_CHECK") != "1":      # a variant whose asm rings the compiler broke measures (and computes) nonsense
+        device_flags = FLAGS.replace("-shared -fPIC", "")
+        r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_asm_stream.py"), "--flags", f"{device_flags} {extra}"],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            print(f"!! variant {name!r}: tools/check_asm_stream.py reports register hazards -- its results and timings are not valid:")
+            print("\n".join(l for l in r.stdout.splitlines() if " 0 hazards" not in l)[:2000])
     return out
 
 
