@@ -71,14 +71,15 @@ def time_stages(pkg, net, ren, o, d, steps, prec=0, full_coarse=False):
     t_sorted = torch.empty(n, 192, device=dev)
     raw_f = torch.empty(n, 192, 4, device=dev)
     rgb, dep = torch.empty(n, 3, device=dev), torch.empty(n, device=dev)
+    raw_f_full = None
     st = L.stream_of(dev)
     # mlp_coarse is the launch nerf_render_forward makes (density-only: the reference reads nothing but sigma of the coarse
     # output when N_importance > 0, volume_renderer.py:335); with --compare-full-coarse, mlp_coarse_full_network times the full
     # coarse network beside it (off by default: its launches would mix into the fine launches' row of `rocprofv3 --stats`)
-    names = ["mlp_coarse_full_network", "mlp_coarse", "sample_fine", "mlp_fine", "composite"]
+    names = ["mlp_coarse_full_network", "mlp_coarse", "sample_fine", "mlp_fine", "composite", "mlp_fine_full_network"]
     acc = dict.fromkeys(names, 0.0)
     for _ in range(steps):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
         ev[0].record()
         if full_coarse:
             L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t_c), 0, n, 64, pk_c.data_ptr(), L.ptr(raw_c), prec, st))
@@ -87,16 +88,26 @@ def time_stages(pkg, net, ren, o, d, steps, prec=0, full_coarse=False):
         ev[2].record()
         L.check(lib.nerf_sample_fine(L.ptr(raw_c), L.ptr(t_c), L.ptr(u), n, L.ptr(t_sorted), None, None, 0.0, 0.0, st))
         ev[3].record()
-        L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t_sorted), 192, n, 192, pk_f.data_ptr(), L.ptr(raw_f), prec, st))
+        L.check(lib.nerf_mlp_forward_rays_for_compositing(L.ptr(o), L.ptr(d), L.ptr(t_sorted), 192, n, 192, pk_f.data_ptr(), L.ptr(raw_f), prec, st))
         ev[4].record()
         L.check(lib.nerf_composite(L.ptr(raw_f), L.ptr(t_sorted), 192, n, 192, 1, L.ptr(rgb), L.ptr(dep), None, st))
         ev[5].record()
+        if full_coarse:        # the fine network with every colour computed (nerf_mlp_forward_rays), into its own buffer
+            if raw_f_full is None:
+                raw_f_full = torch.empty_like(raw_f)
+            L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t_sorted), 192, n, 192, pk_f.data_ptr(), L.ptr(raw_f_full), prec, st))
+        ev[6].record()
         torch.cuda.synchronize()
         for i, k in enumerate(names):
             acc[k] += ev[i].elapsed_time(ev[i + 1])
     if not full_coarse:
-        del acc["mlp_coarse_full_network"]
-    return {k: v / steps for k, v in acc.items()}
+        del acc["mlp_coarse_full_network"], acc["mlp_fine_full_network"]
+    out = {k: v / steps for k, v in acc.items()}
+    # fine tiles (32 consecutive samples) without a single sigma > 0: the fp32 fine launch stops those after the sigma head
+    # (their colours are multiplied by exactly zero in compositing); counted here for the executed-FLOP figure
+    out["_dead_fine_tiles"] = int((raw_f[..., 3] <= 0).reshape(-1, 32).all(-1).sum().item())
+    out["_fine_tiles"] = n * 192 // 32
+    return out
 
 
 def host_cores():
@@ -292,9 +303,10 @@ def main():
                     help="the reference's optional ESS/ERT masked fine pass (volume_renderer.py:132-244, off in lego.yaml): "
                          "fine samples the coarse pass marks empty or occluded skip the MLP; a different image, reported "
                          "as its own metric")
-    ap.add_argument("--compare-full-coarse", action="store_true",
-                    help="also time the FULL coarse network (colour branch included) beside the density-only coarse launch the "
-                         "render makes, and report the frame rate the headline would have with it (profiles/r02_full_coarse_compare.json)")
+    ap.add_argument("--compare-full-coarse", "--compare-full-network", dest="compare_full_coarse", action="store_true",
+                    help="also time the FULL coarse and fine networks (every colour computed) beside the launches the render makes "
+                         "(density-only coarse pass; fine tiles without density stop after the sigma head), and report the frame "
+                         "rate the headline would have with them (profiles/r02_full_network_compare.json)")
     ap.add_argument("--no-extras", dest="extras", action="store_false",
                     help="skip the training (configs[2]) and 1600x1600 f16 (configs[4]) blocks that follow the headline")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32x"],
@@ -398,7 +410,10 @@ def main():
     # 283x128 and rgb_linear 128x3 = 204 288 FLOP per point are never read by the reference's hierarchical render and are
     # not evaluated)
     coarse_flop_per_point = FLOP_PER_POINT - FLOP_DENSITY_SKIPPED
+    dead_tiles, fine_tiles = stages.pop("_dead_fine_tiles"), stages.pop("_fine_tiles")
     flop_frame_executed = (hi - lo) * (64 * coarse_flop_per_point + 192 * FLOP_PER_POINT)
+    if prec == 0:        # only the fp32 kernel skips the colour branch of dead tiles
+        flop_frame_executed -= dead_tiles * 32 * FLOP_DENSITY_SKIPPED
     flop_frame_reference = (hi - lo) * POINTS_PER_RAY * FLOP_PER_POINT
     flop_per_launch = flop_frame_executed / 2.0
     achieved = flop_per_launch / (mlp_ms_per_launch * 1e-3) / 1e12
@@ -413,12 +428,19 @@ def main():
                 "frac": round(achieved / (peak / 1e12), 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": f"nerf_mlp_{args.precision}_kernel", "avg_launch_ms": round(mlp_ms_per_launch, 3),
                 "flop_per_frame_executed": flop_frame_executed, "flop_per_frame_reference_algorithm": flop_frame_reference,
+                "fine_tiles_without_density": {"tiles": dead_tiles, "of": fine_tiles,
+                                               "note": "32-sample tiles whose sigma is <= 0 throughout: weight exactly 0 in compositing; "
+                                                       "the fp32 fine launch stops them after the sigma head (scene-dependent)"},
                 "stage_ms": {k: round(v, 3) for k, v in stages.items()}}
     if args.compare_full_coarse:
         # the same frame with the coarse network evaluated in full (its colour computed and dropped, as the reference
         # does): derived from the measured step time and the two coarse launches timed side by side
         roofline["rays_per_s_if_coarse_colour_were_computed"] = round(
             n / ((ms_per_step + stages["mlp_coarse_full_network"] - stages["mlp_coarse"]) * 1e-3), 1)
+        # ... and with, in addition, the colours of the zero-density fine tiles computed (every FLOP of the reference's algorithm)
+        roofline["rays_per_s_if_every_colour_were_computed"] = round(
+            n / ((ms_per_step + stages["mlp_coarse_full_network"] - stages["mlp_coarse"]
+                  + stages["mlp_fine_full_network"] - stages["mlp_fine"]) * 1e-3), 1)
 
     out = None
     if rank == 0:
@@ -433,7 +455,9 @@ def main():
                                       + ("configs[1]" if H == 800 else "configs[4] frame size" if H == 1600 else "custom frame size"),
                           "coarse_pass": ("density-only launch: sigma is the only coarse output the reference reads when "
                                           "N_importance > 0 (volume_renderer.py:335), rgb/depth are bit-identical to running "
-                                          "the full coarse network (--compare-full-coarse times that beside it: profiles/r02_full_coarse_compare.json)"
+                                          "the full coarse network; fp32 fine launch: 32-sample tiles without a single sigma > 0 stop after the sigma head "
+                                          "too (weight exactly 0 in compositing).  --compare-full-network times the full networks beside "
+                                          "them: profiles/r02_full_network_compare.json"
                                           ),
                           "rays_per_step": n, "parallelism": f"ray-tile shard x{world} (each rank generates and renders only "
                                                              "its tile) + 1 all_gather",

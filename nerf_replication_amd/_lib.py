@@ -29,6 +29,8 @@ _PROTOS = {
     "nerf_mlp_forward": (_c.c_int32, [_F, _F, _c.c_int64, _c.c_int32, _F, _F, _c.c_int32, _c.c_void_p]),
     "nerf_mlp_forward_rays": (_c.c_int32, [_F, _F, _F, _c.c_int64, _c.c_int64, _c.c_int32, _F, _F,
                                            _c.c_int32, _c.c_void_p]),
+    "nerf_mlp_forward_rays_for_compositing": (_c.c_int32, [_F, _F, _F, _c.c_int64, _c.c_int64, _c.c_int32, _F, _F,
+                                                           _c.c_int32, _c.c_void_p]),
     "nerf_mlp_forward_rays_density": (_c.c_int32, [_F, _F, _F, _c.c_int64, _c.c_int64, _c.c_int32, _F, _F,
                                                    _c.c_int32, _c.c_void_p]),
     "nerf_composite_backward": (_c.c_int32, [_F, _F, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _F, _F, _F, _F,

@@ -940,6 +940,8 @@ int launch_mlp(const MlpArgs& a, bool ray_mode, int precision, hipStream_t st) {
   if (blocks > 0x7fffffffLL) return fail(NERF_ERR_INVALID_ARG, "%s", "too many points for one launch");
   // density_only (ray mode): every precision has an instance that stops after the sigma head
   if (ray_mode && a.density_only) hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, false, true>), dim3((unsigned)blocks), dim3(64 * NERF_F32_WG_WAVES), 0, st, a);
+  else if (ray_mode && a.skip_dead_colour && NERF_F32_DEAD_SKIP)
+    hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, false, false, true>), dim3((unsigned)blocks), dim3(64 * NERF_F32_WG_WAVES), 0, st, a);
   else if (ray_mode) hipLaunchKernelGGL(nerf_mlp_f32_kernel<true>, dim3((unsigned)blocks), dim3(64 * NERF_F32_WG_WAVES), 0, st, a);
   else hipLaunchKernelGGL(nerf_mlp_f32_kernel<false>, dim3((unsigned)blocks), dim3(64 * NERF_F32_WG_WAVES), 0, st, a);
   return check_launch("nerf_mlp_f32_kernel");
@@ -1023,6 +1025,19 @@ int32_t nerf_mlp_forward_rays(const float* rays_o, const float* rays_d, const fl
   MlpArgs a{};
   a.rays_o = rays_o; a.rays_d = rays_d; a.tvals = tvals; a.t_ray_stride = t_ray_stride;
   a.n_points = n_rays * n_samples; a.n_samples = n_samples; a.packed = (const float*)packed; a.raw = raw;
+  return launch_mlp(a, true, precision, (hipStream_t)stream);
+}
+
+int32_t nerf_mlp_forward_rays_for_compositing(const float* rays_o, const float* rays_d, const float* tvals,
+                                              int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
+                                              const void* packed, float* raw, int32_t precision, void* stream) {
+  if (n_rays < 0 || n_samples <= 0 || t_ray_stride < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_rays_for_compositing: bad size");
+  if (n_rays == 0) return NERF_OK;
+  if (!rays_o || !rays_d || !tvals || !packed || !raw) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_rays_for_compositing: null argument");
+  MlpArgs a{};
+  a.rays_o = rays_o; a.rays_d = rays_d; a.tvals = tvals; a.t_ray_stride = t_ray_stride;
+  a.n_points = n_rays * n_samples; a.n_samples = n_samples; a.packed = (const float*)packed; a.raw = raw;
+  a.skip_dead_colour = 1;
   return launch_mlp(a, true, precision, (hipStream_t)stream);
 }
 
@@ -1500,7 +1515,8 @@ int32_t nerf_render_forward(const float* rays_o, const float* rays_d, int64_t n_
   if (!fast_sampling) {
     rc = nerf_sample_fine(raw_c, t_coarse, u, n_rays, t_sorted, nullptr, nullptr, 0.f, 0.f, stream);
     if (rc) return rc;
-    rc = nerf_mlp_forward_rays(rays_o, rays_d, t_sorted, S, n_rays, (int32_t)S, packed_fine, raw_f, precision, stream);
+    // the fine outputs only ever reach nerf_composite: colours of zero-density samples are multiplied by exactly 0 there
+    rc = nerf_mlp_forward_rays_for_compositing(rays_o, rays_d, t_sorted, S, n_rays, (int32_t)S, packed_fine, raw_f, precision, stream);
     if (rc) return rc;
   } else {
     // ESS/ERT (volume_renderer.py:359-369, network.py:207-253): only the valid merged samples go through
@@ -1521,6 +1537,7 @@ int32_t nerf_render_forward(const float* rays_o, const float* rays_d, int64_t n_
     MlpArgs a{};
     a.rays_o = rays_o; a.rays_d = rays_d; a.tvals = t_sorted; a.t_ray_stride = S; a.n_points = np;
     a.n_samples = (int)S; a.packed = (const float*)packed_fine; a.raw = raw_f; a.index = index; a.count = count;
+    a.skip_dead_colour = 1;
     rc = launch_mlp(a, true, precision, st);
     if (rc) return rc;
   }

@@ -207,6 +207,50 @@ def test_density_only_forward_is_the_full_forwards_sigma(amd, synthetic_sd, gold
     assert torch.all(dens[..., :3] == 0)
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16", "f32x"])
+@pytest.mark.parametrize("family", ["base", "sharp", "white", "trained"])
+def test_compositing_forward_drops_only_colours_that_are_multiplied_by_zero(amd, golden, family_sd, family, precision):
+    """nerf_mlp_forward_rays_for_compositing (the fine pass of nerf_render_forward) vs nerf_mlp_forward_rays on the reference's
+    own merged depths of every scene family: sigma bit-identical everywhere; rgb bit-identical wherever it is not zeroed; a
+    zeroed colour only at points with sigma <= 0 (weight exactly 0) and, for fp32, exactly in the 32-sample tiles without a
+    single sigma > 0; nerf_composite of the two raw buffers bit-identical.  The families cover 0 % ... 86 % dead tiles."""
+    lib, L = amd._lib.load(), amd._lib
+    g = golden(f"render_family_{family}.npz")
+    net = amd.Network(); net.load_state_dict(family_sd(family)); net = net.cuda().eval(); net.precision = precision
+    prec = L.PRECISIONS[precision]
+    n = 509                                                        # ragged last tile pair
+    o, d = g["pin_rays_o"][:n].cuda().contiguous(), g["pin_rays_d"][:n].cuda().contiguous()
+    t = g["pin_t_sorted"][:n].cuda().contiguous()
+    st = L.stream_of(o.device)
+    pk = net.packed("fine").data_ptr()
+    full = torch.full((n, 192, 4), float("nan"), device="cuda")
+    comp = torch.full((n, 192, 4), float("nan"), device="cuda")
+    L.check(lib.nerf_mlp_forward_rays(L.ptr(o), L.ptr(d), L.ptr(t), 192, n, 192, pk, L.ptr(full), prec, st))
+    L.check(lib.nerf_mlp_forward_rays_for_compositing(L.ptr(o), L.ptr(d), L.ptr(t), 192, n, 192, pk, L.ptr(comp), prec, st))
+    torch.cuda.synchronize()
+    assert torch.isfinite(comp).all()
+    assert torch.equal(comp[..., 3], full[..., 3])
+    dropped = (comp[..., :3] != full[..., :3]).any(-1)              # points whose colour differs at all
+    assert torch.all(comp[..., :3][dropped] == 0)
+    assert torch.all(full[..., 3][dropped] <= 0)
+    dead_tiles = (full[..., 3] <= 0).reshape(n, 6, 32).all(-1)
+    if precision == "f32":
+        live_pts = ~dead_tiles[:, :, None].expand(n, 6, 32).reshape(n, 192)
+        assert not dropped[live_pts].any()                          # every tile with a live point ran in full
+        # (a dead tile whose full colours happen to be exactly 0 would not show up in `dropped`: only an upper bound here)
+        assert dropped.reshape(n, 6, 32).any(-1).sum() <= dead_tiles.sum()
+        if family in ("sharp", "trained", "base"):
+            assert dropped.any(), "fixture lost its dead tiles"
+    else:
+        assert not dropped.any()                                    # these kernels run every tile in full
+    outs = []
+    for raw in (full, comp):
+        rgb, dep = torch.empty(n, 3, device="cuda"), torch.empty(n, device="cuda")
+        L.check(lib.nerf_composite(L.ptr(raw), L.ptr(t), 192, n, 192, 1, L.ptr(rgb), L.ptr(dep), None, st))
+        outs.append((rgb, dep))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_fine_sampling_stage(amd, golden):
     g = golden("sampling.npz")
     lib, L = amd._lib.load(), amd._lib

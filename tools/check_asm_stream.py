@@ -23,9 +23,10 @@ SRC = os.path.join(REPO, "nerf_replication_amd", "csrc", "nerf_kernels.hip")
 # of the library being built; the default below mirrors csrc/Makefile for stand-alone runs
 FLAGS = "-O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950"
 HIPCC = "/opt/rocm/bin/hipcc"
-KERNELS = ["_Z19nerf_mlp_f32_kernelILb1ELb0ELb0EEv7MlpArgs", "_Z19nerf_mlp_f32_kernelILb0ELb0ELb0EEv7MlpArgs",
-           "_Z19nerf_mlp_f32_kernelILb1ELb1ELb0EEv7MlpArgs", "_Z19nerf_mlp_f32_kernelILb0ELb1ELb0EEv7MlpArgs",
-           "_Z19nerf_mlp_f32_kernelILb1ELb1ELb1EEv7MlpArgs", "_Z19nerf_mlp_f32_kernelILb1ELb0ELb1EEv7MlpArgs",
+KERNELS = ["_Z19nerf_mlp_f32_kernelILb1ELb0ELb0ELb0EEv7MlpArgs", "_Z19nerf_mlp_f32_kernelILb0ELb0ELb0ELb0EEv7MlpArgs",
+           "_Z19nerf_mlp_f32_kernelILb1ELb1ELb0ELb0EEv7MlpArgs", "_Z19nerf_mlp_f32_kernelILb0ELb1ELb0ELb0EEv7MlpArgs",
+           "_Z19nerf_mlp_f32_kernelILb1ELb1ELb1ELb0EEv7MlpArgs", "_Z19nerf_mlp_f32_kernelILb1ELb0ELb1ELb0EEv7MlpArgs",
+           "_Z19nerf_mlp_f32_kernelILb1ELb0ELb0ELb1EEv7MlpArgs",
            "_Z23nerf_mlp_bwd_f32_kernelILb0EEv7BwdArgs", "_Z23nerf_mlp_bwd_f32_kernelILb1EEv7BwdArgs",
            "_Z28nerf_wgrad256_f32_asm_kernel10WgradBatch"]
 # every instance of these templates found in the ISA is checked too (their ring depth is part of the mangled name)
