@@ -163,10 +163,19 @@ def run_training(pkg, sd, dev, precision, steps, warmup, world, rank):
     ren = pkg.Renderer(net)
     ids = torch.randperm(H * W, generator=torch.Generator().manual_seed(rank))[:n_rays].to(dev)
     o, d = pkg.generate_rays(camera_pose_40(), H, W, 0.6911112070083618, dev, pixel_ids=ids)
-    colors = torch.rand(n_rays, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+    # targets: the synthetic scene's own render of these rays + 10 % uniform noise.  (Targets of pure noise, the earlier
+    # choice, make the optimiser collapse the density field within a few steps -- 87 % of the backward tiles then carry no
+    # gradient at all and the step time measures the collapse, not the scene the headline renders.)
+    with torch.no_grad():
+        net.eval()
+        rgb0, _ = ren.render({"rays_o": o[None], "rays_d": d[None]})
+        net.train()
+    noise = torch.rand(n_rays, 3, generator=torch.Generator().manual_seed(1)).to(dev) - 0.5
+    colors = (rgb0.reshape(n_rays, 3).float() + 0.1 * noise).clamp_(0.0, 1.0).contiguous()
     opt = FusedAdam(net.parameters(), lr=5e-4, eps=1e-8, clip_value=40.0)      # one launch: clip 40 + Adam
     for _ in range(warmup):
         train_step(ren, opt, o, d, colors)
+    ren.live_tile_stats = []                 # per timed step: live / all 32-point tiles of the two backward passes (device ints)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -182,6 +191,27 @@ def run_training(pkg, sd, dev, precision, steps, warmup, world, rank):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     ms = elapsed / steps * 1e3
+    # live-tile fractions of the timed steps (fp32 backward drops tiles whose incoming gradient is zero throughout: exact)
+    stats, ren.live_tile_stats = ren.live_tile_stats, None
+    live_f = live_c = 1.0
+    if stats and precision == "f32":
+        cf = [int(a.item()) for a, _, _, _ in stats]; cc = [int(c.item()) for _, _, c, _ in stats]
+        if min(cf) >= 0 and min(cc) >= 0:
+            live_f = sum(cf) / (len(cf) * stats[0][1]); live_c = sum(cc) / (len(cc) * stats[0][3])
+    # the same step with the skipping switched off (every tile computed), a few steps right after the timed ones
+    ms_dense = None
+    if precision == "f32" and os.environ.get("NERF_DEAD_TILE_SKIP") != "0":
+        os.environ["NERF_DEAD_TILE_SKIP"] = "0"
+        try:
+            train_step(ren, opt, o, d, colors)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                train_step(ren, opt, o, d, colors)
+            torch.cuda.synchronize()
+            ms_dense = (time.perf_counter() - t1) / 5 * 1e3
+        finally:
+            del os.environ["NERF_DEAD_TILE_SKIP"]
     # fwd + data-grad + weight-grad, per GPU.  The fp32 chain runs the COARSE pass density-only (its colour branch --
     # feature 256x256, views 283x128, rgb 128x3 = 204 288 FLOP per point -- is computed by the reference but never used,
     # SURVEY F6/F10, and skipped here): the roofline counts the FLOP actually executed, not the reference's
@@ -189,6 +219,9 @@ def run_training(pkg, sd, dev, precision, steps, warmup, world, rank):
     # (f32x: its chain kernels still run the coarse colour branch -- on zeros --, only the three weight-gradient jobs are skipped)
     skipped = n_rays * 64 * 204288 * (3.0 if precision == "f32" else 1.0)
     flop = flop_ref - skipped
+    if precision == "f32":       # forward in full; the two backward thirds only on live tiles
+        fwd_f, fwd_c = n_rays * 192 * FLOP_PER_POINT, n_rays * 64 * (FLOP_PER_POINT - 204288)
+        flop = (fwd_f + fwd_c) + 2.0 * (fwd_f * live_f + fwd_c * live_c)
     # f32x: three fp16 (or six bf16) MFMAs per algorithmic MAC -> ceiling = a third of the fp16 peak
     peak = PEAK_F32_MFMA if precision == "f32" else PEAK_F16_MFMA / 3.0
     traffic = None
@@ -201,6 +234,11 @@ def run_training(pkg, sd, dev, precision, steps, warmup, world, rank):
             "roofline": {"bound": "mfma", "achieved": round(flop / (ms * 1e-3) / 1e12, 2), "peak": round(peak / 1e12, 1),
                          "unit": "TFLOP/s", "frac": round(flop / (ms * 1e-3) / peak, 4), "traffic": traffic,
                          "flop_per_step_executed": flop, "flop_per_step_reference_algorithm": flop_ref},
+            "live_tile_fraction": {"fine": round(live_f, 4), "coarse": round(live_c, 4),
+                                   "note": "32-point tiles with a non-zero incoming gradient, mean over the timed steps; the fp32 "
+                                           "backward skips the others (exact: d loss / d raw is zero wherever relu(sigma) = 0); "
+                                           "scene- and step-dependent"},
+            "ms_per_step_without_dead_tile_skip": None if ms_dense is None else round(ms_dense, 3),
             "final_loss": round(loss.item(), 6)}
 
 
@@ -218,9 +256,12 @@ def train_bench(pkg, sd, dev, args, world, rank):
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": TRAIN_DTYPE[precision], "data": "synthetic",
-                          "config": {"workload": "BASELINE.json configs[2]: 4096 rays/iter per GPU, MSE on fine RGB, clip 40, "
-                                                 "Adam 5e-4; data parallel: one 4.77 MB gradient all-reduce per step"},
-                          "roofline": r["roofline"], "final_loss": r["final_loss"]}), flush=True)
+                          "config": {"workload": "BASELINE.json configs[2]: 4096 rays/iter per GPU, MSE on fine RGB (targets: the synthetic "
+                                                 "scene's own render + 10 % noise), clip 40, Adam 5e-4; data parallel: one 4.77 MB "
+                                                 "gradient all-reduce per step"},
+                          "roofline": r["roofline"], "final_loss": r["final_loss"],
+                          "live_tile_fraction": r["live_tile_fraction"],
+                          "ms_per_step_without_dead_tile_skip": r["ms_per_step_without_dead_tile_skip"]}), flush=True)
 
 
 def run_config5(pkg, sd, dev, world, rank, steps=2):

@@ -40,6 +40,7 @@ _PROTOS = {
                                     _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_int64), _c.c_float, _c.c_float, _c.c_float,
                                     _c.c_float, _c.c_float, _c.c_float, _c.c_int64, _c.c_void_p]),
     "nerf_train_grad_floats": (_c.c_int64, [_c.c_int64]),
+    "nerf_train_live_count_offset": (_c.c_int64, [_c.c_int64]),
     "nerf_packed_bwd_bytes": (_c.c_int64, [_c.c_int32]),
     "nerf_pack_model_bwd": (_c.c_int32, [_c.POINTER(_c.c_void_p), _F, _c.c_int32, _c.c_void_p]),
     "nerf_mlp_backward": (_c.c_int32, [_F, _F, _F, _c.c_int64, _c.c_int64, _c.c_int32, _F, _F, _F, _F, _F,

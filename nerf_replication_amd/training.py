@@ -91,6 +91,9 @@ class RenderFunction(torch.autograd.Function):
                                              pk_b.data_ptr(), _lib.ptr(g_raw_f), _lib.ptr(save_f), _lib.ptr(gsave),
                                              _lib.ptr(g_t_pts), _ptr_array(grads[24:]), prec, st), "nerf_mlp_backward(fine)")
             g_t.add_(g_t_pts)                     # plumbing: one elementwise add of two [n,192] buffers
+            cnt_f = None
+            if getattr(renderer, "live_tile_stats", None) is not None:
+                cnt_f = gsave[int(lib.nerf_train_live_count_offset(n * S_f))].view(torch.int32).clone()
             # coarse pass: depths -> coarse density -> coarse MLP parameters
             g_raw_c = torch.empty((n, S_c, 4), **f32)
             _lib.check(lib.nerf_sample_fine_backward(_lib.ptr(raw_c), _lib.ptr(t_c), _lib.ptr(u), n, _lib.ptr(t_sorted),
@@ -100,6 +103,12 @@ class RenderFunction(torch.autograd.Function):
             _lib.check(lib.nerf_mlp_backward_density(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t_c), 0, n, S_c,
                                                      pk_b.data_ptr(), _lib.ptr(g_raw_c), _lib.ptr(save_c), _lib.ptr(gsave_c),
                                                      None, _ptr_array(grads[:24]), prec, st), "nerf_mlp_backward(coarse)")
+            stats = getattr(renderer, "live_tile_stats", None)
+            if stats is not None:
+                # (live tiles, tiles) of the coarse pass as 1-element device tensors: no host sync here; the fine pass's
+                # count was cloned above, before its gsave was reused
+                cnt_c = gsave_c[int(lib.nerf_train_live_count_offset(n * S_c))].view(torch.int32).clone()
+                stats.append((cnt_f, n * S_f // 32, cnt_c, n * S_c // 32))
         return (None, None, None) + tuple(g.to(p.dtype) for g, p in zip(grads, params))
 
 

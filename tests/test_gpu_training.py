@@ -502,3 +502,66 @@ def test_density_only_pair_equals_full_pair_with_zero_colour_gradient(amd, net, 
             assert torch.all(gf == 0) and torch.all(gd == 0), name
         else:
             assert gf.abs().max() > 0 and _rel(gd, gf.cpu()) <= 2e-6, name
+
+
+@pytest.mark.parametrize("density_only", [False, True])
+@pytest.mark.parametrize("dead_frac", [0.0, 0.6, 1.0])
+def test_dead_tile_skip_changes_nothing(amd, net, synthetic_sd, monkeypatch, dead_frac, density_only):
+    """Tiles (32 consecutive points) whose d loss / d raw is zero throughout are dropped from the chain launch and from every
+    weight-gradient launch (nerf_tile_flags_kernel -> live-tile list).  Against the same call with NERF_DEAD_TILE_SKIP=0:
+    d loss / d t equal as numbers everywhere (bit-identical code on live tiles, 0 on dead ones), all 24 parameter gradients
+    equal to the rounding of their atomic accumulation -- for no dead tile, a scene-like 60 %, and all of them (gradients
+    exactly zero).  Zeros include -0.0; a tile with ONE live point is live."""
+    import ctypes
+    lib, L = amd._lib.load(), amd._lib
+    gen = torch.Generator().manual_seed(31)
+    n, S = 48, 192                                            # 288 tiles; with dead_frac 0.6 about 115 stay live
+    model = ""
+    o = torch.tensor([0.0, 0.0, 4.0]).expand(n, 3).contiguous().cuda()
+    d = torch.randn(n, 3, generator=gen) * 0.2 + torch.tensor([0.0, 0.0, -1.0])
+    d = (d / d.norm(dim=-1, keepdim=True)).contiguous().cuda()
+    t = torch.sort(torch.rand(n, S, generator=gen) * 4 + 2, dim=-1).values.cuda().contiguous()
+    G = torch.randn(n, S, 4, generator=gen) * 1e-3
+    tiles = G.view(-1, 32, 4)
+    dead = torch.rand(tiles.shape[0], generator=gen) < dead_frac
+    tiles[dead] = 0.0
+    if dead_frac == 0.6:
+        k = int(dead.nonzero()[0])
+        tiles[k, 7, 3] = 2e-4                                  # one live point (sigma channel): the tile must run
+        tiles[int(dead.nonzero()[1])] = -0.0                   # negative zeros are zeros
+    if density_only:
+        tiles[..., :3] = 0.0
+    G = G.cuda().contiguous()
+    params = [p.detach().contiguous() for p in net.model.ordered_params()]
+    arr = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in params])
+    st = L.stream_of(o.device)
+    pk_b = torch.empty(int(lib.nerf_packed_bwd_bytes(0)), dtype=torch.uint8, device="cuda")
+    L.check(lib.nerf_pack_model_bwd(arr, pk_b.data_ptr(), 0, st))
+    P = n * S
+    fwd = lib.nerf_mlp_forward_rays_save_density if density_only else lib.nerf_mlp_forward_rays_save
+    bwd = lib.nerf_mlp_backward_density if density_only else lib.nerf_mlp_backward
+    raw = torch.empty((n, S, 4), device="cuda")
+    save = torch.empty(int(lib.nerf_train_save_floats(P)), device="cuda")
+    L.check(fwd(L.ptr(o), L.ptr(d), L.ptr(t), S, n, S, net.packed(model).data_ptr(), L.ptr(raw), L.ptr(save), 0, st))
+    out = {}
+    for tag, env in (("skip", "1"), ("dense", "0")):
+        monkeypatch.setenv("NERF_DEAD_TILE_SKIP", env)
+        gsave = torch.full((int(lib.nerf_train_grad_floats(P)),), float("nan"), device="cuda")     # dead rows stay NaN: never read
+        g_t = torch.full((n, S), float("nan"), device="cuda")
+        grads = [torch.zeros_like(p) for p in params]
+        L.check(bwd(L.ptr(o), L.ptr(d), L.ptr(t), S, n, S, pk_b.data_ptr(), L.ptr(G), L.ptr(save), L.ptr(gsave), L.ptr(g_t),
+                    _grad_ptrs(amd, grads), 0, st))
+        torch.cuda.synchronize()
+        out[tag] = (g_t, grads)
+    monkeypatch.delenv("NERF_DEAD_TILE_SKIP")
+    assert torch.isfinite(out["skip"][0]).all()
+    assert torch.all(out["skip"][0] == out["dense"][0])                     # equal as numbers (0 == -0)
+    names = list(__import__("nerf_oracle").SUBMODEL_KEYS)
+    for name, gs, gd in zip(names, out["skip"][1], out["dense"][1]):
+        assert torch.isfinite(gs).all(), name
+        if dead_frac == 1.0:
+            assert torch.all(gs == 0) and torch.all(gd == 0), name
+        elif density_only and name.startswith(("views_linears", "feature_linear", "rgb_linear")):
+            assert torch.all(gs == 0) and torch.all(gd == 0), name
+        else:
+            assert gd.abs().max() > 0 and _rel(gs, gd.cpu()) <= 2e-6, name
