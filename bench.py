@@ -150,7 +150,7 @@ def cpu_baseline(sd, n_sample, budget_s=20.0):
                       f"(os.cpu_count()={os.cpu_count()})"}, (ids, rgb, dep)
 
 
-def run_training(pkg, sd, dev, precision, steps, warmup, world, rank):
+def run_training(pkg, sd, dev, precision, steps, warmup, world, rank, compare_dense=True):
     """BASELINE config 3: 4096 rays per iteration per GPU (4 x 1024 random pixels), forward with activation save,
     backward through the adjoint kernels, [one gradient all-reduce], clip 40, Adam lr 5e-4 -- the reference's
     intended step.  One "step" = one iteration.  Returns the measured block (max over ranks)."""
@@ -200,7 +200,7 @@ def run_training(pkg, sd, dev, precision, steps, warmup, world, rank):
             live_f = sum(cf) / (len(cf) * stats[0][1]); live_c = sum(cc) / (len(cc) * stats[0][3])
     # the same step with the skipping switched off (every tile computed), a few steps right after the timed ones
     ms_dense = None
-    if precision == "f32" and os.environ.get("NERF_DEAD_TILE_SKIP") != "0":
+    if compare_dense and precision == "f32" and os.environ.get("NERF_DEAD_TILE_SKIP") != "0":
         os.environ["NERF_DEAD_TILE_SKIP"] = "0"
         try:
             train_step(ren, opt, o, d, colors)
@@ -249,7 +249,7 @@ TRAIN_DTYPE = {"f32": "f32", "f32x": "f32x (split-fp16 fwd/bwd chains, bf16x3 we
 def train_bench(pkg, sd, dev, args, world, rank):
     """`--mode train`: the config-3 step as its own JSON line (what profiles/collect.sh profiles)."""
     precision = args.precision if args.precision in ("f32", "f32x") else "f32"
-    r = run_training(pkg, sd, dev, precision, args.steps, args.warmup, world, rank)
+    r = run_training(pkg, sd, dev, precision, args.steps, args.warmup, world, rank, compare_dense=args.compare_dense)
     if rank == 0:
         print(json.dumps({"metric": "rays/sec (training, 4096 rays/iter, 64+128, fwd+bwd+Adam)",
                           "value": r["rays_per_s"], "unit": "rays/s", "n_gpus": world,
@@ -348,6 +348,9 @@ def main():
                     help="also time the FULL coarse and fine networks (every colour computed) beside the launches the render makes "
                          "(density-only coarse pass; fine tiles without density stop after the sigma head), and report the frame "
                          "rate the headline would have with them (profiles/r02_full_network_compare.json)")
+    ap.add_argument("--no-dense-compare", dest="compare_dense", action="store_false",
+                    help="--mode train: do not append the six steps with NERF_DEAD_TILE_SKIP=0 that give "
+                         "ms_per_step_without_dead_tile_skip (profiles/collect.sh: keeps the rocprofv3 rows of the timed steps clean)")
     ap.add_argument("--no-extras", dest="extras", action="store_false",
                     help="skip the training (configs[2]) and 1600x1600 f16 (configs[4]) blocks that follow the headline")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32x"],
