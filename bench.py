@@ -221,7 +221,9 @@ def run_training(pkg, sd, dev, precision, steps, warmup, world, rank, compare_de
     flop = flop_ref - skipped
     if precision == "f32":       # forward in full; the two backward thirds only on live tiles
         fwd_f, fwd_c = n_rays * 192 * FLOP_PER_POINT, n_rays * 64 * (FLOP_PER_POINT - 204288)
-        flop = (fwd_f + fwd_c) + 2.0 * (fwd_f * live_f + fwd_c * live_c)
+        # (the fine forward also drops the colour branch of its density-free tiles: counted as every backward-dead tile,
+        # which can only under-count what was executed)
+        flop = (fwd_f - (1.0 - live_f) * n_rays * 192 * 204288 + fwd_c) + 2.0 * (fwd_f * live_f + fwd_c * live_c)
     # f32x: three fp16 (or six bf16) MFMAs per algorithmic MAC -> ceiling = a third of the fp16 peak
     peak = PEAK_F32_MFMA if precision == "f32" else PEAK_F16_MFMA / 3.0
     traffic = None

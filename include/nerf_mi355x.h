@@ -148,6 +148,16 @@ int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float*
  * stops after the sigma head (raw = (0, 0, 0, sigma); feature / views rows are not stored), the backward starts at
  * g_h7 = w_alpha * g_sigma and leaves the three colour gradients as zeroed by the caller.  `draw`'s rgb columns are not
  * read.  `save` from the density forward must go to the density backward.  NERF_PREC_F32X: same as the full calls. */
+/* nerf_mlp_forward_rays_save for a fine pass whose `raw` goes to nerf_composite and whose `draw` will come from
+ * nerf_composite_backward (training.RenderFunction): NERF_PREC_F32 stops a 32-point tile without a single sigma > 0 after the
+ * sigma head (rgb = 0 there, as nerf_mlp_forward_rays_for_compositing) and stores nothing past its h6 row.  CONTRACT: the `draw`
+ * later given to nerf_mlp_backward with this `save` must be zero wherever sigma <= 0 -- nerf_composite_backward guarantees it --
+ * so that the backward pass, which skips tiles with a zero incoming gradient, never reads those rows.  With
+ * NERF_DEAD_TILE_SKIP=0 in the environment (or a point count that is not a multiple of 32, or NERF_PREC_F32X) this is
+ * nerf_mlp_forward_rays_save. */
+int32_t nerf_mlp_forward_rays_save_for_compositing(const float* rays_o, const float* rays_d, const float* tvals,
+                                                   int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
+                                                   const void* packed, float* raw, float* save, int32_t precision, void* stream);
 int32_t nerf_mlp_forward_rays_save_density(const float* rays_o, const float* rays_d, const float* tvals,
                                            int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
                                            const void* packed, float* raw, float* save, int32_t precision, void* stream);

@@ -58,6 +58,8 @@ _PROTOS = {
     "nerf_train_save_floats": (_c.c_int64, [_c.c_int64]),
     "nerf_mlp_forward_rays_save": (_c.c_int32, [_F, _F, _F, _c.c_int64, _c.c_int64, _c.c_int32, _F, _F, _F, _c.c_int32,
                                                 _c.c_void_p]),
+    "nerf_mlp_forward_rays_save_for_compositing": (_c.c_int32, [_F, _F, _F, _c.c_int64, _c.c_int64, _c.c_int32, _F, _F, _F, _c.c_int32,
+                                                _c.c_void_p]),
     "nerf_sample_fine": (_c.c_int32, [_F, _F, _F, _c.c_int64, _F, _F, _F, _c.c_float, _c.c_float, _c.c_void_p]),
     "nerf_composite": (_c.c_int32, [_F, _F, _c.c_int64, _c.c_int64, _c.c_int32, _c.c_int32, _F, _F, _F,
                                     _c.c_void_p]),

@@ -1504,7 +1504,8 @@ int64_t nerf_train_save_floats(int64_t n_points) { return n_points < 0 ? -1 : Tr
 
 static int32_t forward_rays_save_impl(const float* rays_o, const float* rays_d, const float* tvals,
                                       int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
-                                      const void* packed, float* raw, float* save, int32_t precision, void* stream, int density_only) {
+                                      const void* packed, float* raw, float* save, int32_t precision, void* stream, int density_only,
+                                      int skip_dead = 0) {
   if (n_rays < 0 || n_samples <= 0 || t_ray_stride < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_rays_save: bad size");
   if (n_rays == 0) return NERF_OK;
   if (!rays_o || !rays_d || !tvals || !packed || !raw || !save) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_rays_save: null argument");
@@ -1523,6 +1524,7 @@ static int32_t forward_rays_save_impl(const float* rays_o, const float* rays_d, 
   if (tiles > 0x7fffffffLL) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_rays_save: too many points for one launch");
   // barrier-free: one-wave workgroups
   if (density_only) hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, true, true>), dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, a);
+  else if (skip_dead && NERF_F32_DEAD_SKIP) hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, true, false, true>), dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, true>), dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, a);
   return check_launch("nerf_mlp_f32_kernel<save>");
 }
@@ -1531,6 +1533,14 @@ int32_t nerf_mlp_forward_rays_save(const float* rays_o, const float* rays_d, con
                                    int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
                                    const void* packed, float* raw, float* save, int32_t precision, void* stream) {
   return forward_rays_save_impl(rays_o, rays_d, tvals, t_ray_stride, n_rays, n_samples, packed, raw, save, precision, stream, 0);
+}
+int32_t nerf_mlp_forward_rays_save_for_compositing(const float* rays_o, const float* rays_d, const float* tvals,
+                                                   int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
+                                                   const void* packed, float* raw, float* save, int32_t precision, void* stream) {
+  // without dead-tile skipping in the backward pass every row must exist: fall back to the full store
+  const char* env = getenv("NERF_DEAD_TILE_SKIP");
+  const int skip = !(env && env[0] == '0') && (n_rays * (int64_t)n_samples) % 32 == 0;
+  return forward_rays_save_impl(rays_o, rays_d, tvals, t_ray_stride, n_rays, n_samples, packed, raw, save, precision, stream, 0, skip);
 }
 int32_t nerf_mlp_forward_rays_save_density(const float* rays_o, const float* rays_d, const float* tvals,
                                            int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,

@@ -44,7 +44,9 @@ class RenderFunction(torch.autograd.Function):
                                                               pk_c.data_ptr(), _lib.ptr(raw_c), _lib.ptr(save_c), prec, st), "forward(coarse)")
             _lib.check(lib.nerf_sample_fine(_lib.ptr(raw_c), _lib.ptr(t_c), _lib.ptr(u), n, _lib.ptr(t_sorted), None, None,
                                             0.0, 0.0, st), "nerf_sample_fine")
-            _lib.check(lib.nerf_mlp_forward_rays_save(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t_sorted), S_f, n, S_f,
+            # fine pass: its raw goes to compositing only, and its gradient will come from compositing's adjoint (zero
+            # wherever sigma <= 0): tiles without density skip the colour branch and its stores (exact, see the header)
+            _lib.check(lib.nerf_mlp_forward_rays_save_for_compositing(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t_sorted), S_f, n, S_f,
                                                       pk_f.data_ptr(), _lib.ptr(raw_f), _lib.ptr(save_f), prec, st), "forward(fine)")
             _lib.check(lib.nerf_composite(_lib.ptr(raw_f), _lib.ptr(t_sorted), S_f, n, S_f, int(bool(renderer.white_bkgd)),
                                           _lib.ptr(rgb), _lib.ptr(depth), None, st), "nerf_composite")

@@ -26,7 +26,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 KERNELS = ["_Z19nerf_mlp_f32_kernelILb1ELb0ELb0ELb0EEv7MlpArgs", "_Z19nerf_mlp_f32_kernelILb0ELb0ELb0ELb0EEv7MlpArgs",
            "_Z19nerf_mlp_f32_kernelILb1ELb1ELb0ELb0EEv7MlpArgs", "_Z19nerf_mlp_f32_kernelILb0ELb1ELb0ELb0EEv7MlpArgs",
            "_Z19nerf_mlp_f32_kernelILb1ELb1ELb1ELb0EEv7MlpArgs", "_Z19nerf_mlp_f32_kernelILb1ELb0ELb1ELb0EEv7MlpArgs",
-           "_Z19nerf_mlp_f32_kernelILb1ELb0ELb0ELb1EEv7MlpArgs",
+           "_Z19nerf_mlp_f32_kernelILb1ELb0ELb0ELb1EEv7MlpArgs", "_Z19nerf_mlp_f32_kernelILb1ELb1ELb0ELb1EEv7MlpArgs",
            "_Z23nerf_mlp_bwd_f32_kernelILb0EEv7BwdArgs", "_Z23nerf_mlp_bwd_f32_kernelILb1EEv7BwdArgs",
            "_Z28nerf_wgrad256_f32_asm_kernelILb0EEv10WgradBatch", "_Z28nerf_wgrad256_f32_asm_kernelILb1EEv10WgradBatch"]
 # every instance of these templates found in the ISA is checked too (their ring depth is part of the mangled name)
