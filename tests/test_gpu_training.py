@@ -564,7 +564,7 @@ def test_dead_tile_skip_changes_nothing(amd, net, synthetic_sd, monkeypatch, dea
         elif density_only and name.startswith(("views_linears", "feature_linear", "rgb_linear")):
             assert torch.all(gs == 0) and torch.all(gd == 0), name
         else:
-            assert gd.abs().max() > 0 and _rel(gs, gd.cpu()) <= 2e-6, name
+            assert gd.abs().max() > 0 and _rel(gs, gd.cpu()) <= 1e-5, name      # (sums of ~10^4 signed terms, accumulated by atomics in a different order)
 
 
 @pytest.mark.parametrize("family", ["base", "sharp", "trained"])
