@@ -194,13 +194,13 @@ def run_training(pkg, sd, dev, precision, steps, warmup, world, rank, compare_de
     # live-tile fractions of the timed steps (fp32 backward drops tiles whose incoming gradient is zero throughout: exact)
     stats, ren.live_tile_stats = ren.live_tile_stats, None
     live_f = live_c = 1.0
-    if stats and precision == "f32":
+    if stats:
         cf = [int(a.item()) for a, _, _, _ in stats]; cc = [int(c.item()) for _, _, c, _ in stats]
         if min(cf) >= 0 and min(cc) >= 0:
             live_f = sum(cf) / (len(cf) * stats[0][1]); live_c = sum(cc) / (len(cc) * stats[0][3])
     # the same step with the skipping switched off (every tile computed), a few steps right after the timed ones
     ms_dense = None
-    if compare_dense and precision == "f32" and os.environ.get("NERF_DEAD_TILE_SKIP") != "0":
+    if compare_dense and os.environ.get("NERF_DEAD_TILE_SKIP") != "0":
         os.environ["NERF_DEAD_TILE_SKIP"] = "0"
         try:
             train_step(ren, opt, o, d, colors)
@@ -219,6 +219,9 @@ def run_training(pkg, sd, dev, precision, steps, warmup, world, rank, compare_de
     # (f32x: its chain kernels still run the coarse colour branch -- on zeros --, only the three weight-gradient jobs are skipped)
     skipped = n_rays * 64 * 204288 * (3.0 if precision == "f32" else 1.0)
     flop = flop_ref - skipped
+    if precision == "f32x":      # forward in full (coarse colour branch included); the two backward thirds only on live tiles
+        fwd_f, fwd_c = n_rays * 192 * FLOP_PER_POINT, n_rays * 64 * FLOP_PER_POINT
+        flop = (fwd_f + fwd_c) + (fwd_f * live_f + fwd_c * live_c) + (fwd_f * live_f + n_rays * 64 * (FLOP_PER_POINT - 204288) * live_c)
     if precision == "f32":       # forward in full; the two backward thirds only on live tiles
         fwd_f, fwd_c = n_rays * 192 * FLOP_PER_POINT, n_rays * 64 * (FLOP_PER_POINT - 204288)
         # (the fine forward also drops the colour branch of its density-free tiles: counted as every backward-dead tile,

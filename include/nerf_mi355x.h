@@ -127,11 +127,11 @@ int32_t nerf_mlp_forward_rays_save(const float* rays_o, const float* rays_d, con
  * themselves and accepts a `save` of either forward.  Both `save` and `gsave` regions hold their rows padded to a
  * multiple of 32 points (offsets are derived from the padded count, see csrc/nerf_mlp_f32.hip.inc TrainSave). */
 int64_t nerf_train_grad_floats(int64_t n_points);
-/* Dead-tile skipping (NERF_PREC_F32, n_points a multiple of 32; exact): a tile of 32 consecutive points whose `draw` rows are
+/* Dead-tile skipping (n_points a multiple of 32; exact): a tile of 32 consecutive points whose `draw` rows are
  * all zero has zero g_z rows, adds nothing to any parameter gradient and has zero g_t / g_x -- compositing writes such rows
  * wherever relu(sigma) = 0.  nerf_mlp_backward* drop those tiles from the chain launch and from every weight-gradient launch
  * (their rows in `gsave` are then left unwritten).  The number of live tiles of the call is left as an int32 at float offset
- * nerf_train_live_count_offset(n_points) of `gsave` (-1: the call ran without a list: other precision, ragged n_points, or
+ * nerf_train_live_count_offset(n_points) of `gsave` (-1: the call ran without a list: ragged n_points, or
  * NERF_DEAD_TILE_SKIP=0 in the environment, which turns the skipping off for A/B comparisons). */
 int64_t nerf_train_live_count_offset(int64_t n_points);
 int64_t nerf_packed_bwd_bytes(int32_t precision);

@@ -1339,14 +1339,15 @@ static int32_t mlp_backward_impl(const BwdArgs& a_in, bool pts_mode, float* cons
   const long long P = a.n_points;
   const float* draw = a.draw; const float* save = a.save; float* gsave = a.gsave;
   int rc;
-  // live tiles (fp32 path): tiles whose incoming gradient is zero throughout are dropped from the chain launch and from every
+  // live tiles: tiles whose incoming gradient is zero throughout are dropped from the chain launch and from every
   // weight-gradient launch -- see nerf_tile_flags_kernel.  Needs the asm-ring weight-gradient kernels (whole 32-point tiles).
   // NERF_DEAD_TILE_SKIP=0 in the environment turns it off (tests compare the two).
   const int* live = nullptr; const int* n_live = nullptr;
   {
     const char* env = getenv("NERF_DEAD_TILE_SKIP");
     const bool want = !(env && env[0] == '0');
-    if (want && precision == NERF_PREC_F32 && NERF_WGRAD_ASM && NERF_WGVEC_ASM && P % 32 == 0 && P / 32 <= 0x7fffffffLL) {
+    if (want && (precision == NERF_PREC_F32 || precision == NERF_PREC_F32X) && NERF_WGRAD_ASM && NERF_WGVEC_ASM && P % 32 == 0 &&
+        P / 32 <= 0x7fffffffLL) {
       int* flags = reinterpret_cast<int*>(gsave + TrainGrad::off_flags(P));
       int* lv = reinterpret_cast<int*>(gsave + TrainGrad::off_live(P));
       int* cnt = reinterpret_cast<int*>(gsave + TrainGrad::off_count(P));
@@ -1406,7 +1407,7 @@ static int32_t mlp_backward_impl(const BwdArgs& a_in, bool pts_mode, float* cons
   if (precision == NERF_PREC_F32X) {
     // the eight 256 x 256 blocks in one launch on the bf16x3 path (nerf_wgrad_bf16x3.hip.inc)
     WgradXArgs w;
-    w.n_points = P; w.n_jobs = 0;
+    w.n_points = P; w.n_jobs = 0; w.live_tiles = live; w.n_live = n_live;
     auto job = [&](const float* dz, const float* hin, float* dw, int ldw, int wc0, float* db) {
       WgradXJob& j = w.job[w.n_jobs++];
       j.dz = dz; j.hin = hin; j.dw = dw; j.db = db; j.ldz = 256; j.zc0 = 0; j.ldh = 256; j.hc0 = 0; j.ldw = ldw; j.wc0 = wc0;   // ld 256: the kernel assumes 1-KiB rows

@@ -504,9 +504,10 @@ def test_density_only_pair_equals_full_pair_with_zero_colour_gradient(amd, net, 
             assert gf.abs().max() > 0 and _rel(gd, gf.cpu()) <= 2e-6, name
 
 
+@pytest.mark.parametrize("precision", ["f32", "f32x"])
 @pytest.mark.parametrize("density_only", [False, True])
 @pytest.mark.parametrize("dead_frac", [0.0, 0.6, 1.0])
-def test_dead_tile_skip_changes_nothing(amd, net, synthetic_sd, monkeypatch, dead_frac, density_only):
+def test_dead_tile_skip_changes_nothing(amd, net, synthetic_sd, monkeypatch, dead_frac, density_only, precision):
     """Tiles (32 consecutive points) whose d loss / d raw is zero throughout are dropped from the chain launch and from every
     weight-gradient launch (nerf_tile_flags_kernel -> live-tile list).  Against the same call with NERF_DEAD_TILE_SKIP=0:
     d loss / d t equal as numbers everywhere (bit-identical code on live tiles, 0 on dead ones), all 24 parameter gradients
@@ -514,6 +515,8 @@ def test_dead_tile_skip_changes_nothing(amd, net, synthetic_sd, monkeypatch, dea
     exactly zero).  Zeros include -0.0; a tile with ONE live point is live."""
     import ctypes
     lib, L = amd._lib.load(), amd._lib
+    net.precision = precision
+    prec = L.PRECISIONS[precision]
     gen = torch.Generator().manual_seed(31)
     n, S = 48, 192                                            # 288 tiles; with dead_frac 0.6 about 115 stay live
     model = ""
@@ -535,14 +538,14 @@ def test_dead_tile_skip_changes_nothing(amd, net, synthetic_sd, monkeypatch, dea
     params = [p.detach().contiguous() for p in net.model.ordered_params()]
     arr = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in params])
     st = L.stream_of(o.device)
-    pk_b = torch.empty(int(lib.nerf_packed_bwd_bytes(0)), dtype=torch.uint8, device="cuda")
-    L.check(lib.nerf_pack_model_bwd(arr, pk_b.data_ptr(), 0, st))
+    pk_b = torch.empty(int(lib.nerf_packed_bwd_bytes(prec)), dtype=torch.uint8, device="cuda")
+    L.check(lib.nerf_pack_model_bwd(arr, pk_b.data_ptr(), prec, st))
     P = n * S
     fwd = lib.nerf_mlp_forward_rays_save_density if density_only else lib.nerf_mlp_forward_rays_save
     bwd = lib.nerf_mlp_backward_density if density_only else lib.nerf_mlp_backward
     raw = torch.empty((n, S, 4), device="cuda")
     save = torch.empty(int(lib.nerf_train_save_floats(P)), device="cuda")
-    L.check(fwd(L.ptr(o), L.ptr(d), L.ptr(t), S, n, S, net.packed(model).data_ptr(), L.ptr(raw), L.ptr(save), 0, st))
+    L.check(fwd(L.ptr(o), L.ptr(d), L.ptr(t), S, n, S, net.packed(model).data_ptr(), L.ptr(raw), L.ptr(save), prec, st))
     out = {}
     for tag, env in (("skip", "1"), ("dense", "0")):
         monkeypatch.setenv("NERF_DEAD_TILE_SKIP", env)
@@ -550,10 +553,11 @@ def test_dead_tile_skip_changes_nothing(amd, net, synthetic_sd, monkeypatch, dea
         g_t = torch.full((n, S), float("nan"), device="cuda")
         grads = [torch.zeros_like(p) for p in params]
         L.check(bwd(L.ptr(o), L.ptr(d), L.ptr(t), S, n, S, pk_b.data_ptr(), L.ptr(G), L.ptr(save), L.ptr(gsave), L.ptr(g_t),
-                    _grad_ptrs(amd, grads), 0, st))
+                    _grad_ptrs(amd, grads), prec, st))
         torch.cuda.synchronize()
         out[tag] = (g_t, grads)
     monkeypatch.delenv("NERF_DEAD_TILE_SKIP")
+    net.precision = "f32"
     assert torch.isfinite(out["skip"][0]).all()
     assert torch.all(out["skip"][0] == out["dense"][0])                     # equal as numbers (0 == -0)
     names = list(__import__("nerf_oracle").SUBMODEL_KEYS)
@@ -567,8 +571,9 @@ def test_dead_tile_skip_changes_nothing(amd, net, synthetic_sd, monkeypatch, dea
             assert gd.abs().max() > 0 and _rel(gs, gd.cpu()) <= 1e-5, name      # (sums of ~10^4 signed terms, accumulated by atomics in a different order)
 
 
+@pytest.mark.parametrize("precision", ["f32", "f32x"])
 @pytest.mark.parametrize("family", ["base", "sharp", "trained"])
-def test_training_step_same_with_and_without_dead_tile_skipping(amd, family_sd, family, monkeypatch):
+def test_training_step_same_with_and_without_dead_tile_skipping(amd, family_sd, family, monkeypatch, precision):
     """A whole step (render_with_grad -> MSE -> backward) on scenes with 17 % ... 86 % density-free fine tiles, the product path
     (fine forward stores nothing past h6 for tiles without density, backward on live tiles only) against
     NERF_DEAD_TILE_SKIP=0 (every row stored, every tile computed): rgb / depth bit-identical, all 48 gradients equal to the
@@ -577,7 +582,7 @@ def test_training_step_same_with_and_without_dead_tile_skipping(amd, family_sd, 
     out = {}
     for tag, env in (("skip", "1"), ("dense", "0")):
         monkeypatch.setenv("NERF_DEAD_TILE_SKIP", env)
-        net = amd.Network(); net.load_state_dict(family_sd(family)); net = net.cuda().train(); net.precision = "f32"
+        net = amd.Network(); net.load_state_dict(family_sd(family)); net = net.cuda().train(); net.precision = precision
         ren = amd.Renderer(net)
         ren.live_tile_stats = []
         gen = torch.Generator().manual_seed(5)
