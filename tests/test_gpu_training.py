@@ -607,4 +607,4 @@ def test_training_step_same_with_and_without_dead_tile_skipping(amd, family_sd, 
         if gd.abs().max() == 0:
             assert torch.all(gs == 0)
         else:
-            assert _rel(gs, gd.cpu()) <= 2e-5
+            assert _rel(gs, gd.cpu()) <= 1e-4            # (atomic accumulation order; scalar sums with cancellation reach 5e-5)
