@@ -141,13 +141,6 @@ int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float*
                           const float* save, float* gsave, float* g_t, float* const grads[24], int32_t precision,
                           void* stream);
 
-/* Density-only twins for the COARSE pass of a training step.  In the reference's step only the coarse sigma is ever used
- * (it places the fine samples; the coarse colour is never composited, volume_renderer.py:385-397, SURVEY F6/F10), so
- * d loss / d raw_coarse has identically zero rgb columns and the gradients of rgb_linear, views_linears.0 and
- * feature_linear of the coarse sub-model are exactly zero.  With NERF_PREC_F32 these entries skip that branch: the forward
- * stops after the sigma head (raw = (0, 0, 0, sigma); feature / views rows are not stored), the backward starts at
- * g_h7 = w_alpha * g_sigma and leaves the three colour gradients as zeroed by the caller.  `draw`'s rgb columns are not
- * read.  `save` from the density forward must go to the density backward.  NERF_PREC_F32X: same as the full calls. */
 /* nerf_mlp_forward_rays_save for a fine pass whose `raw` goes to nerf_composite and whose `draw` will come from
  * nerf_composite_backward (training.RenderFunction): NERF_PREC_F32 stops a 32-point tile without a single sigma > 0 after the
  * sigma head (rgb = 0 there, as nerf_mlp_forward_rays_for_compositing) and stores nothing past its h6 row.  CONTRACT: the `draw`
@@ -158,6 +151,14 @@ int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float*
 int32_t nerf_mlp_forward_rays_save_for_compositing(const float* rays_o, const float* rays_d, const float* tvals,
                                                    int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
                                                    const void* packed, float* raw, float* save, int32_t precision, void* stream);
+
+/* Density-only twins for the COARSE pass of a training step.  In the reference's step only the coarse sigma is ever used
+ * (it places the fine samples; the coarse colour is never composited, volume_renderer.py:385-397, SURVEY F6/F10), so
+ * d loss / d raw_coarse has identically zero rgb columns and the gradients of rgb_linear, views_linears.0 and
+ * feature_linear of the coarse sub-model are exactly zero.  With NERF_PREC_F32 these entries skip that branch: the forward
+ * stops after the sigma head (raw = (0, 0, 0, sigma); feature / views rows are not stored), the backward starts at
+ * g_h7 = w_alpha * g_sigma and leaves the three colour gradients as zeroed by the caller.  `draw`'s rgb columns are not
+ * read.  `save` from the density forward must go to the density backward.  NERF_PREC_F32X: same as the full calls. */
 int32_t nerf_mlp_forward_rays_save_density(const float* rays_o, const float* rays_d, const float* tvals,
                                            int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
                                            const void* packed, float* raw, float* save, int32_t precision, void* stream);
@@ -184,7 +185,8 @@ int32_t nerf_viewdirs_backward(const float* gsave, int64_t n_rays, int32_t n_sam
 
 /* Adjoint of nerf_composite (autograd of volume_renderer.py:414-432 with :67-96): g_rgb [n,3], g_depth [n]
  * (nullable) -> g_raw [n,S,4] and, if given, g_t [n,S] (the direct dependence of the image on the sample
- * depths through delta_k = t_{k+1}-t_k and the depth sum). */
+ * depths through delta_k = t_{k+1}-t_k and the depth sum).  S <= 192.  Rows of g_raw are exactly zero wherever
+ * sigma <= 0 (relu: alpha = 0, weight 0) -- what the dead-tile skipping of nerf_mlp_backward* feeds on. */
 int32_t nerf_composite_backward(const float* raw, const float* tvals, int64_t t_ray_stride, int64_t n_rays,
                                 int32_t n_samples, int32_t white_bkgd, const float* g_rgb, const float* g_depth,
                                 float* g_raw, float* g_t, void* stream);

@@ -540,15 +540,20 @@ void nerf_composite_staged_kernel(const float* __restrict__ raw, const float* __
 //   w_k = T_k a_k, T_k = prod_{j<k} q_j, q = clamp(1-a, 1e-10, 1), a = 1 - exp(-relu(s) delta), delta_k = t_{k+1}-t_k
 //   rgb = sum w_k sigmoid(r_k) + (1 - sum w_k) [white], depth = sum w_k t_k
 // Given g_rgb [n,3], g_depth [n] -> g_raw [n,S,4], g_t [n,S] (direct dependence through delta and depth).
-constexpr int kBwdRowPitch = 193;
-__global__ __launch_bounds__(64)
+// One WAVE per ray (a training step has 4096 rays: with one thread per ray the 2 x 192 sequential steps of 64 lonely waves were
+// 108 us of dependent instruction latency): lane l owns samples l, l + 64, l + 128, the transmittance is a wave-level
+// exclusive prefix product and the suffix sum a wave-level exclusive suffix sum, chunk by chunk with a scalar carry; every
+// load and store is one coalesced row segment.  (The scans associate differently from the forward's sequential product:
+// rounding-level differences in T, as between any two summation orders.)
+constexpr int kCbMaxSamples = 192;
+__global__ __launch_bounds__(256)
 void nerf_composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ tvals, long long t_ray_stride,
                                long long n_rays, int S, int white_bkgd, const float* __restrict__ g_rgb,
                                const float* __restrict__ g_depth, float* __restrict__ g_raw, float* __restrict__ g_t) {
-  __shared__ float s_T[64 * kBwdRowPitch];              // transmittance T_k of the forward sweep (S <= 192)
-  const long long ray = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (ray >= n_rays) return;
-  float* Tk_row = s_T + threadIdx.x * kBwdRowPitch;
+  constexpr int C = kCbMaxSamples / 64;
+  const int lane = threadIdx.x & 63;
+  const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= n_rays) return;                                   // (wave-uniform)
   const f32x4* r4 = reinterpret_cast<const f32x4*>(raw) + ray * S;
   f32x4* g4 = reinterpret_cast<f32x4*>(g_raw) + ray * S;
   const float* t = tvals + ray * t_ray_stride;
@@ -556,79 +561,80 @@ void nerf_composite_bwd_kernel(const float* __restrict__ raw, const float* __res
   const float gr = g_rgb[ray * 3 + 0], gg = g_rgb[ray * 3 + 1], gb = g_rgb[ray * 3 + 2];
   const float gd = g_depth ? g_depth[ray] : 0.0f;
   const float wb = white_bkgd ? 1.0f : 0.0f;
-  // One thread per ray means one exposed HBM latency per sequential step unless the loads are issued ahead of the scan:
-  // both sweeps fetch kCbBatch steps (raw quads + depths, clamped to the row) into registers first, then scan them.
-  constexpr int kCbBatch = 16;
-  {
-    float T = 1.0f;
-    for (int k0 = 0; k0 < S; k0 += kCbBatch) {
-      float sg[kCbBatch], tt[kCbBatch + 1];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  f32x4 v[C];
+  float tk[C], delta[C], e[C], alpha[C], om[C], q[C], Tk[C], g_delta[C], gt_own[C];
+  // forward sweep: T_k = prod_{j<k} q_j
+  float carry = 1.0f;
 #pragma unroll
-      for (int j = 0; j < kCbBatch; ++j) sg[j] = r4[min(k0 + j, S - 1)].w;
+  for (int c = 0; c < C; ++c) {
+    const int k = 64 * c + lane;
+    const bool live = k < S;
+    v[c] = live ? r4[k] : zero4;
+    tk[c] = live ? t[k] : 0.0f;
+    const float tn = (k + 1 < S) ? t[k + 1] : tk[c];
+    delta[c] = (k < S - 1) ? __fsub_rn(tn, tk[c]) : 1e10f;
+    const float sig = fmaxf(v[c].w, 0.0f);
+    e[c] = expf(__fmul_rn(-sig, delta[c]));
+    alpha[c] = __fsub_rn(1.0f, e[c]);
+    om[c] = __fsub_rn(1.0f, alpha[c]);
+    q[c] = live ? fminf(fmaxf(om[c], 1e-10f), 1.0f) : 1.0f;
+    float p = q[c];                                            // inclusive prefix product over the 64 lanes
 #pragma unroll
-      for (int j = 0; j <= kCbBatch; ++j) tt[j] = t[min(k0 + j, S - 1)];
+    for (int d = 1; d < 64; d <<= 1) {
+      const float o = __shfl_up(p, d);
+      if (lane >= d) p *= o;
+    }
+    float excl = __shfl_up(p, 1);
+    if (lane == 0) excl = 1.0f;
+    Tk[c] = carry * excl;
+    carry *= __shfl(p, 63);
+  }
+  // reverse sweep: suf_k = sum_{m>k} g_w_m a_m T_m;  g_q_k = suf_k / q_k
+  float carry_s = 0.0f;
 #pragma unroll
-      for (int j = 0; j < kCbBatch; ++j) {
-        const int k = k0 + j;
-        if (k < S) {
-          Tk_row[k] = T;
-          const float sig = fmaxf(sg[j], 0.0f);
-          const float delta = (k < S - 1) ? __fsub_rn(tt[j + 1], tt[j]) : 1e10f;
-          const float alpha = alpha_of(sig, delta);
-          T = __fmul_rn(T, fminf(fmaxf(__fsub_rn(1.0f, alpha), 1e-10f), 1.0f));
-        }
-      }
+  for (int c = C - 1; c >= 0; --c) {
+    const int k = 64 * c + lane;
+    const bool live = k < S;
+    const float sig = fmaxf(v[c].w, 0.0f);
+    const float cr = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v[c].x)));
+    const float cg = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v[c].y)));
+    const float cb = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v[c].z)));
+    const float g_w = gr * (cr - wb) + gg * (cg - wb) + gb * (cb - wb) + gd * tk[c];
+    const float w = Tk[c] * alpha[c];
+    float sfx = live ? g_w * alpha[c] * Tk[c] : 0.0f;           // inclusive suffix sum over the 64 lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const float o = __shfl_down(sfx, d);
+      if (lane + d < 64) sfx += o;
+    }
+    float excl = __shfl_down(sfx, 1);
+    if (lane == 63) excl = 0.0f;
+    const float suf = excl + carry_s;
+    carry_s += __shfl(sfx, 0);
+    float g_alpha = g_w * Tk[c];
+    if (om[c] >= 1e-10f && om[c] <= 1.0f) g_alpha -= suf / q[c];      // clamp passes the gradient inside its range
+    const float g_sig = g_alpha * delta[c] * e[c];
+    g_delta[c] = (k < S - 1) ? g_alpha * sig * e[c] : 0.0f;
+    f32x4 go;
+    go.x = gr * w * cr * (1.0f - cr);
+    go.y = gg * w * cg * (1.0f - cg);
+    go.z = gb * w * cb * (1.0f - cb);
+    go.w = v[c].w > 0.0f ? g_sig : 0.0f;
+    if (live) g4[k] = go;
+    gt_own[c] = gd * w - g_delta[c];                            // delta_k = t_{k+1} - t_k: - g_delta_k here, + g_delta_{k-1} below
+  }
+  if (gt) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int k = 64 * c + lane;
+      float prev = __shfl_up(g_delta[c], 1);
+      const float last_of_prev_chunk = c > 0 ? __shfl(g_delta[c > 0 ? c - 1 : 0], 63) : 0.0f;
+      if (lane == 0) prev = last_of_prev_chunk;
+      if (k < S) gt[k] = gt_own[c] + prev;
     }
   }
-  // reverse: suf = sum_{m>k} g_T_m T_m  (g_T_m = g_w_m a_m);  g_q_k = suf / q_k
-  float suf = 0.0f;
-  float gt_pending = 0.0f;                                   // gd w_{k+1} - g_delta_{k+1}: g_t[k + 1] is written once, complete,
-                                                             // when step k supplies + g_delta_k (no read-modify-write in memory)
-  for (int k1 = (S + kCbBatch - 1) / kCbBatch * kCbBatch; k1 > 0; k1 -= kCbBatch) {
-    const int k0 = k1 - kCbBatch;
-    f32x4 vv[kCbBatch];
-    float tt[kCbBatch + 1];
-#pragma unroll
-    for (int j = 0; j < kCbBatch; ++j) vv[j] = r4[min(k0 + j, S - 1)];
-#pragma unroll
-    for (int j = 0; j <= kCbBatch; ++j) tt[j] = t[min(k0 + j, S - 1)];
-#pragma unroll
-    for (int j = kCbBatch - 1; j >= 0; --j) {
-      const int k = k0 + j;
-      if (k >= S) continue;
-      const f32x4 v = vv[j];
-      const float sig = fmaxf(v.w, 0.0f);
-      const float tk = tt[j];
-      const float delta = (k < S - 1) ? __fsub_rn(tt[j + 1], tk) : 1e10f;
-      const float e = expf(__fmul_rn(-sig, delta));
-      const float alpha = __fsub_rn(1.0f, e);
-      const float om = __fsub_rn(1.0f, alpha);
-      const float q = fminf(fmaxf(om, 1e-10f), 1.0f);
-      const float Tk = Tk_row[k];
-      const float cr = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v.x)));
-      const float cg = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v.y)));
-      const float cb = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-v.z)));
-      const float g_w = gr * (cr - wb) + gg * (cg - wb) + gb * (cb - wb) + gd * tk;
-      const float w = Tk * alpha;
-      float g_alpha = g_w * Tk;
-      if (om >= 1e-10f && om <= 1.0f) g_alpha -= suf / q;      // clamp passes the gradient inside its range
-      suf += g_w * alpha * Tk;                                 // g_T_k T_k joins the suffix for smaller k
-      const float g_sig = g_alpha * delta * e;
-      const float g_delta = (k < S - 1) ? g_alpha * sig * e : 0.0f;
-      f32x4 go;
-      go.x = gr * w * cr * (1.0f - cr);
-      go.y = gg * w * cg * (1.0f - cg);
-      go.z = gb * w * cb * (1.0f - cb);
-      go.w = v.w > 0.0f ? g_sig : 0.0f;
-      g4[k] = go;
-      if (gt) {
-        // delta_k = t_{k+1} - t_k:  g_t[k] = gd w_k - g_delta_k (+ g_delta_{k-1}, known one step later)
-        if (k < S - 1) gt[k + 1] = gt_pending + g_delta;
-        gt_pending = gd * w - g_delta;
-      }
-    }
-  }
-  if (gt) gt[0] = gt_pending;
 }
 
 // Backward of hierarchical sampling (volume_renderer.py:126-154, :247-264 under autograd): gradient of the
@@ -1247,7 +1253,8 @@ int32_t nerf_composite_backward(const float* raw, const float* tvals, int64_t t_
   if (n_rays < 0 || n_samples <= 0 || t_ray_stride < 0) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_composite_backward: bad size");
   if (n_rays == 0) return NERF_OK;
   if (!raw || !tvals || !g_rgb || !g_raw) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_composite_backward: null argument");
-  hipLaunchKernelGGL(nerf_composite_bwd_kernel, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, (hipStream_t)stream, raw, tvals,
+  if (n_samples > kCbMaxSamples) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_composite_backward: at most 192 samples per ray");
+  hipLaunchKernelGGL(nerf_composite_bwd_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, raw, tvals,
                      (long long)t_ray_stride, (long long)n_rays, n_samples, white_bkgd, g_rgb, g_depth, g_raw, g_t);
   return check_launch("nerf_composite_bwd_kernel");
 }
