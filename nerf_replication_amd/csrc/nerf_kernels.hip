@@ -640,54 +640,80 @@ void nerf_composite_bwd_kernel(const float* __restrict__ raw, const float* __res
 // Backward of hierarchical sampling (volume_renderer.py:126-154, :247-264 under autograd): gradient of the
 // merged depths w.r.t. the coarse densities (the coarse table and u are constants).  Recomputes the
 // forward quantities, then: g_t_fine -> g_cdf[below/above] -> g_pdf (reverse cumsum) -> g_(w+eps) ->
-// g_w (inner 62) -> g_sigma through T/alpha -> g_raw_coarse[..., 3] (relu mask).  One thread per ray.
-__global__ __launch_bounds__(kSampleThreads)
+// g_w (inner 62) -> g_sigma through T/alpha -> g_raw_coarse[..., 3] (relu mask).
+// One WAVE per ray, lane i = coarse sample i (S = 64), two fine samples per lane.  What decides where a fine sample falls --
+// transmittance, the running sum of the weights and the cdf -- is recomputed in the forward's own SEQUENTIAL order (a
+// v_readlane walk over the lanes with the forward's rounding intrinsics: bit-identical bins); everything downstream of the
+// decisions is a gradient and uses wave scans / LDS atomics.  (One thread per ray took 131 us for the 4096 rays of a step:
+// 64 lonely waves whose data-dependent while-loops also ran in lockstep.)
+__device__ __forceinline__ float lane_bcast(float v, int lane_const) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_const));
+}
+__global__ __launch_bounds__(256)
 void nerf_sample_bwd_kernel(const float* __restrict__ raw_c, const float* __restrict__ t_coarse,
                             const float* __restrict__ u_tab, long long n_rays, const float* __restrict__ t_sorted,
                             const float* __restrict__ g_tsorted, float* __restrict__ g_raw_c) {
   constexpr int S = NERF_N_SAMPLES, F = NERF_N_IMPORTANCE, NB = S - 1;
+  static_assert(S == 64 && F == 128, "lane = coarse sample, two fine samples per lane");
   __shared__ float s_tc[S];
   __shared__ float s_u[F];
-  __shared__ float s_cdf[kSampleThreads * (NB + 2)];       // cdf, later g_cdf
-  __shared__ float s_gw[kSampleThreads * (S + 1)];         // g_cdf accumulator
-  __shared__ float s_T[kSampleThreads * (S + 1)];          // transmittance T_i of the coarse sweep
-  const int lane = threadIdx.x;
-  s_tc[lane] = t_coarse[lane];
-  s_u[lane] = u_tab[lane]; s_u[lane + 64] = u_tab[lane + 64];
+  __shared__ float s_cdf[4][S];
+  __shared__ float s_gcdf[4][S];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x < S) s_tc[threadIdx.x] = t_coarse[threadIdx.x];
+  if (threadIdx.x < F) s_u[threadIdx.x] = u_tab[threadIdx.x];
+  s_gcdf[wv][lane] = 0.0f;
   __syncthreads();
-  const long long ray = (long long)blockIdx.x * kSampleThreads + lane;
-  if (ray >= n_rays) return;
-  const float* sig_p = raw_c + ray * (S * 4) + 3;
-  float* cdf = s_cdf + lane * (NB + 2);
-  float* gw = s_gw + lane * (S + 1);
-  float* Ti = s_T + lane * (S + 1);
-  // ---- forward recompute: w+eps, sum, cdf
-  float T = 1.0f, wsum = 0.0f;
-  for (int i = 0; i < S; ++i) {
-    Ti[i] = T;
-    const float sigma = fmaxf(sig_p[i * 4], 0.0f);
-    const float delta = (i < S - 1) ? __fsub_rn(s_tc[i + 1], s_tc[i]) : 1e10f;
-    const float alpha = alpha_of(sigma, delta);
-    const float w = __fmul_rn(T, alpha);
-    if (i >= 1 && i <= S - 2) { const float we = __fadd_rn(w, 1e-5f); cdf[i - 1] = we; wsum = __fadd_rn(wsum, we); }
-    T = __fmul_rn(T, fminf(fmaxf(__fsub_rn(1.0f, alpha), 1e-10f), 1.0f));
-    gw[i] = 0.0f;
-  }
+  const long long ray_slot = (long long)blockIdx.x * 4 + wv;
+  const bool ray_ok = ray_slot < n_rays;                       // a wave past the end recomputes the last ray and stores nothing
+  const long long ray = ray_ok ? ray_slot : n_rays - 1;        // (it has to reach the two workgroup barriers below)
+  (void)t_sorted;
+  const int i = lane;
+  // ---- forward recompute, in the forward's order and rounding (nerf_sample_fine_kernel)
+  const float s_raw = raw_c[ray * (S * 4) + i * 4 + 3];
+  const float sigma = fmaxf(s_raw, 0.0f);
+  const float delta = (i < S - 1) ? __fsub_rn(s_tc[i + 1], s_tc[i]) : 1e10f;
+  const float e = expf(__fmul_rn(-sigma, delta));
+  const float alpha = __fsub_rn(1.0f, e);                      // = alpha_of(sigma, delta)
+  const float om = __fsub_rn(1.0f, alpha);
+  const float q = fminf(fmaxf(om, 1e-10f), 1.0f);
+  float Ti = 1.0f;
   {
-    float run = 0.0f, prev = cdf[0];
-    cdf[0] = 0.0f;
-    for (int m = 1; m < NB; ++m) { run = __fadd_rn(run, __fdiv_rn(prev, wsum)); prev = cdf[m]; cdf[m] = run; }
+    float T = 1.0f;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      if (lane == j) Ti = T;
+      T = __fmul_rn(T, lane_bcast(q, j));
+    }
   }
-  // ---- g_t_fine[k]: the merged position of fine sample k (coarse first on ties, as in the forward merge)
-  // and its adjoint into g_cdf; g_cdf accumulated in registers-free fashion: second LDS row would double the
-  // footprint, so accumulate into gw[] scratch indexed by cdf entry (63 <= 65 slots), then convert.
-  float* gcdf = gw;                                    // reuse: 63 entries
+  const bool inner = i >= 1 && i <= S - 2;
+  const float we = __fadd_rn(__fmul_rn(Ti, alpha), 1e-5f);     // w + eps (used for the inner 62 only)
+  float wsum = 0.0f;
+#pragma unroll
+  for (int j = 1; j <= S - 2; ++j) wsum = __fadd_rn(wsum, lane_bcast(we, j));
+  const float pdf = __fdiv_rn(we, wsum);                       // lane i: pdf of bin i - 1
+  float cdf_m = 0.0f;                                          // lane m: cdf[m], m = 0..62
+  {
+    float run = 0.0f;
+#pragma unroll
+    for (int m = 1; m < NB; ++m) {
+      run = __fadd_rn(run, lane_bcast(pdf, m));
+      if (lane == m) cdf_m = run;
+    }
+  }
+  s_cdf[wv][lane] = cdf_m;                                     // (lane 63: unused slot)
+  __syncthreads();
+  // ---- the two fine samples of this lane: bin, merged slot, adjoint into g_cdf
   const float* gts = g_tsorted + ray * (S + F);
-  const float* ts = t_sorted + ray * (S + F);
-  int ind = 0, ic = 0;                                 // ic = coarse samples already merged before fine k
-  for (int k = 0; k < F; ++k) {
+  float* cdf = s_cdf[wv];
+  float* gcdf = s_gcdf[wv];
+  int ic_carry = 0;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int k = lane + 64 * half;
     const float u = s_u[k];
-    while (ind < NB && cdf[ind] <= u) ++ind;
+    int ind = 0;
+    for (int m = 0; m < NB; ++m) ind += cdf[m] <= u;            // cdf is non-decreasing: = the forward's searchsorted(right)
     const int below = min(max(ind - 1, 0), S - 3), above = min(ind, S - 3);
     const float cb = cdf[below], ca = cdf[above];
     const float bb = __fmul_rn(0.5f, __fadd_rn(s_tc[below + 1], s_tc[below]));
@@ -697,53 +723,52 @@ void nerf_sample_bwd_kernel(const float* __restrict__ raw_c, const float* __rest
     const float denom = live ? draw_ : 1.0f;
     const float num = __fsub_rn(u, cb);
     const float v = __fadd_rn(bb, __fmul_rn(__fdiv_rn(num, denom), __fsub_rn(ba, bb)));
-    while (ic < S && s_tc[ic] <= v) ++ic;              // coarse entries sorted before this fine sample
-    const float g = gts[k + ic];                       // its slot in the merged array
-    (void)ts;
+    int ic = 0;                                                 // coarse entries sorted before this fine sample (ties: coarse first)
+    for (int j = 0; j < S; ++j) ic += s_tc[j] <= v;
+    // the forward's merge pointer never moves back: running maximum over the fine samples in order
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(ic, d);
+      if (lane >= d) ic = max(ic, o);
+    }
+    ic = max(ic, ic_carry);
+    ic_carry = __shfl(ic, 63);
+    const float g = gts[k + ic];                                // its slot in the merged array
     const float g_frac = g * __fsub_rn(ba, bb);
-    // frac = (u - cb) / denom, denom = ca - cb when live
-    float g_cb = -g_frac / denom, g_ca = 0.0f;
+    float g_cb = -g_frac / denom, g_ca = 0.0f;                  // frac = (u - cb) / denom, denom = ca - cb when live
     if (live) { const float gden = -g_frac * num / (denom * denom); g_ca += gden; g_cb -= gden; }
-    gcdf[below] += g_cb;
-    gcdf[above] += g_ca;
+    atomicAdd(&gcdf[below], g_cb);
+    atomicAdd(&gcdf[above], g_ca);
   }
-  // ---- cdf[m] = sum_{i<m} pdf_i  ->  g_pdf_i = sum_{m>i} g_cdf[m];  pdf = we / W
-  // first pass: g_pdf and sum_j g_pdf_j we_j  (we_j recomputed from cdf differences is inexact: recompute weights)
-  float acc = 0.0f;
-  for (int i = NB - 2; i >= 0; --i) { acc += gcdf[i + 1]; cdf[i] = acc; }      // cdf[i] now holds g_pdf_i (i = 0..61)
-  // recompute we_i to form the pdf backward, then the weights backward in one reverse sweep
-  float dot = 0.0f;
-  {
-    float T2 = 1.0f;
-    for (int i = 0; i < S; ++i) {
-      const float sigma = fmaxf(sig_p[i * 4], 0.0f);
-      const float delta = (i < S - 1) ? __fsub_rn(s_tc[i + 1], s_tc[i]) : 1e10f;
-      const float alpha = alpha_of(sigma, delta);
-      const float w = __fmul_rn(T2, alpha);
-      if (i >= 1 && i <= S - 2) dot += cdf[i - 1] * __fadd_rn(w, 1e-5f);
-      T2 = __fmul_rn(T2, fminf(fmaxf(__fsub_rn(1.0f, alpha), 1e-10f), 1.0f));
-    }
-    float suf = 0.0f;
-    f32x4* g4 = reinterpret_cast<f32x4*>(g_raw_c) + ray * S;
-    for (int i = S - 1; i >= 0; --i) {
-      const float s_raw = sig_p[i * 4];
-      const float sigma = fmaxf(s_raw, 0.0f);
-      const float delta = (i < S - 1) ? __fsub_rn(s_tc[i + 1], s_tc[i]) : 1e10f;
-      const float e = expf(__fmul_rn(-sigma, delta));
-      const float alpha = __fsub_rn(1.0f, e);
-      const float om = __fsub_rn(1.0f, alpha);
-      const float q = fminf(fmaxf(om, 1e-10f), 1.0f);
-      const float Tk = Ti[i];
-      const float g_w = (i >= 1 && i <= S - 2) ? (cdf[i - 1] / wsum - dot / (wsum * wsum)) : 0.0f;
-      float g_alpha = g_w * Tk;
-      const float g_q = suf / q;
-      if (om >= 1e-10f && om <= 1.0f) g_alpha -= g_q;
-      suf += g_w * alpha * Tk;
-      f32x4 go = {0.f, 0.f, 0.f, 0.f};
-      go.w = s_raw > 0.0f ? g_alpha * delta * e : 0.0f;
-      g4[i] = go;
-    }
+  __syncthreads();
+  // ---- cdf[m] = sum_{j<m} pdf_j  ->  g_pdf_j = sum_{m>j} g_cdf[m];  pdf = we / W
+  float sfx = lane < NB ? gcdf[lane] : 0.0f;                    // inclusive suffix sum over the lanes
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_down(sfx, d);
+    if (lane + d < 64) sfx += o;
   }
+  float gpdf_excl = __shfl_down(sfx, 1);                        // lane j: g_pdf_j = sum_{m>j} g_cdf[m]
+  if (lane == 63) gpdf_excl = 0.0f;
+  float gpdf_i = __shfl_up(gpdf_excl, 1);                       // lane i: g_pdf of bin i - 1 (the bin of sample i)
+  if (!inner) gpdf_i = 0.0f;
+  float dot = inner ? gpdf_i * we : 0.0f;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) dot += __shfl_xor(dot, d);
+  const float g_w = inner ? (gpdf_i / wsum - dot / (wsum * wsum)) : 0.0f;
+  float sf2 = g_w * alpha * Ti;                                 // suf_i = sum_{m>i} g_w_m a_m T_m
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_down(sf2, d);
+    if (lane + d < 64) sf2 += o;
+  }
+  float suf = __shfl_down(sf2, 1);
+  if (lane == 63) suf = 0.0f;
+  float g_alpha = g_w * Ti;
+  if (om >= 1e-10f && om <= 1.0f) g_alpha -= suf / q;
+  f32x4 go = {0.f, 0.f, 0.f, 0.f};
+  go.w = s_raw > 0.0f ? g_alpha * delta * e : 0.0f;
+  if (ray_ok) reinterpret_cast<f32x4*>(g_raw_c)[ray * S + i] = go;
 }
 
 // ------------------------------------------------------------------------------------ training: live tiles of a backward pass
@@ -1265,7 +1290,7 @@ int32_t nerf_sample_fine_backward(const float* raw_coarse, const float* t_coarse
   if (n_rays == 0) return NERF_OK;
   if (!raw_coarse || !t_coarse || !u || !t_sorted || !g_t_sorted || !g_raw_coarse)
     return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_sample_fine_backward: null argument");
-  hipLaunchKernelGGL(nerf_sample_bwd_kernel, dim3((unsigned)((n_rays + kSampleThreads - 1) / kSampleThreads)), dim3(kSampleThreads), 0,
+  hipLaunchKernelGGL(nerf_sample_bwd_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0,
                      (hipStream_t)stream, raw_coarse, t_coarse, u, (long long)n_rays, t_sorted, g_t_sorted, g_raw_coarse);
   return check_launch("nerf_sample_bwd_kernel");
 }
