@@ -608,3 +608,50 @@ def test_training_step_same_with_and_without_dead_tile_skipping(amd, family_sd, 
             assert torch.all(gs == 0)
         else:
             assert _rel(gs, gd.cpu()) <= 1e-4            # (atomic accumulation order; scalar sums with cancellation reach 5e-5)
+
+
+@pytest.mark.parametrize("n_sub", [1, 5, 63])
+def test_per_ray_adjoints_are_independent_of_the_ray_count(amd, golden, n_sub):
+    """The compositing and sampler adjoints run one wave per ray, four rays per workgroup: a ray count that leaves waves of the
+    last workgroup without a ray (1, 5, 63) must give exactly the rows the same rays get inside a larger call; S = 64 and 192
+    for compositing (one and three 64-lane chunks; shared and per-ray depth tables)."""
+    g = golden("sampling.npz")
+    lib, L = amd._lib.load(), amd._lib
+    gen = torch.Generator().manual_seed(77)
+    st = L.stream_of(torch.device("cuda:0"))
+    n_all = 64
+    for S, raw_key, t_all, stride in ((192, "raw_fine", g["t_sorted"][:n_all].cuda().contiguous(), 192),
+                                      (64, "raw_coarse", torch.linspace(2.0, 6.0, 64).cuda(), 0)):
+        raw = g[raw_key][:n_all].clone()
+        raw[..., 3] *= 0.2
+        raw = raw.cuda().contiguous()
+        Gr = torch.randn(n_all, 3, generator=gen).cuda().contiguous()
+        Gd = torch.randn(n_all, generator=gen).cuda().contiguous()
+        outs = []
+        for n in (n_all, n_sub):
+            g_raw = torch.full((n_all, S, 4), float("nan"), device="cuda")
+            g_t = torch.full((n_all, S), float("nan"), device="cuda")
+            L.check(lib.nerf_composite_backward(L.ptr(raw), L.ptr(t_all), stride, n, S, 1, L.ptr(Gr), L.ptr(Gd), L.ptr(g_raw), L.ptr(g_t), st))
+            torch.cuda.synchronize()
+            outs.append((g_raw, g_t))
+        assert torch.equal(outs[0][0][:n_sub], outs[1][0][:n_sub]) and torch.equal(outs[0][1][:n_sub], outs[1][1][:n_sub])
+        assert torch.isnan(outs[1][0][n_sub:]).all() and torch.isnan(outs[1][1][n_sub:]).all()          # nothing written past the count
+        assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+    raw_c = g["raw_coarse"][:n_all].cuda().contiguous()
+    tcd, ud = torch.linspace(2.0, 6.0, 64).cuda(), torch.linspace(0.0, 1.0, 128).cuda()
+    ts = torch.empty(n_all, 192, device="cuda")
+    L.check(lib.nerf_sample_fine(L.ptr(raw_c), L.ptr(tcd), L.ptr(ud), n_all, L.ptr(ts), None, None, 0.0, 0.0, st))
+    G = torch.randn(n_all, 192, generator=gen).cuda().contiguous()
+    outs = []
+    for n in (n_all, n_sub):
+        g_raw = torch.full((n_all, 64, 4), float("nan"), device="cuda")
+        L.check(lib.nerf_sample_fine_backward(L.ptr(raw_c), L.ptr(tcd), L.ptr(ud), n, L.ptr(ts), L.ptr(G), L.ptr(g_raw), st))
+        torch.cuda.synchronize()
+        outs.append(g_raw)
+    # (LDS float atomics accumulate the few contributions per cdf entry in arbitrary order: equal to rounding, not bit for bit)
+    ref, got = outs[0][:n_sub, :, 3], outs[1][:n_sub, :, 3]
+    assert ((ref - got).abs().amax(dim=1) <= 1e-5 * ref.abs().amax(dim=1).clamp_min(1e-20)).all()
+    assert torch.isnan(outs[1][n_sub:]).all()
+    # S > 192 is refused, not silently mis-indexed
+    rc = lib.nerf_composite_backward(L.ptr(raw_c), L.ptr(tcd), 0, 1, 193, 1, L.ptr(Gr), None, L.ptr(outs[0]), None, st)
+    assert rc != 0 and b"192" in lib.nerf_last_error()
