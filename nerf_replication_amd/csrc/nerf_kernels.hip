@@ -165,15 +165,15 @@ __device__ __forceinline__ float f16_stream_value(const PackArgs& a, int F, int 
     const int f = F - kF16FragL5, m = f / 20, s = f % 20;
     if (s < 4) { const int c = pe_xyz_feat(8 * s + j, h); if (c >= 0) v = a.p[10][(32 * m + row) * 319 + c]; }
     else v = a.p[10][(32 * m + row) * 319 + 63 + 16 * (s - 4) + cj];
-  } else if (F < kF16FragFeat) {                              // L6, L7
+  } else if (F < kF16FragSigma) {                             // L6, L7
     const int f = F - kF16FragL6, li = 6 + (f >> 7), m = (f & 127) >> 4, s = f & 15;
     v = a.p[2 * li][(32 * m + row) * 256 + 16 * s + cj];
-  } else if (F < kF16FragSigma) {                             // feature
-    const int f = F - kF16FragFeat, m = f >> 4, s = f & 15;
-    v = a.p[P_WF][(32 * m + row) * 256 + 16 * s + cj];
-  } else if (F < kF16FragViews) {                             // sigma head: row 0 only
+  } else if (F < kF16FragFeat) {                              // sigma head: row 0 only
     const int s = F - kF16FragSigma;
     if (row == 0) v = a.p[P_WA][16 * s + cj];
+  } else if (F < kF16FragViews) {                             // feature
+    const int f = F - kF16FragFeat, m = f >> 4, s = f & 15;
+    v = a.p[P_WF][(32 * m + row) * 256 + 16 * s + cj];
   } else if (F < kF16FragRgb) {                               // views: 16 feature + 2 dir k-steps per m
     const int f = F - kF16FragViews, m = f / 18, s = f % 18;
     if (s < 16) v = a.p[P_WV][(32 * m + row) * 283 + 16 * s + cj];

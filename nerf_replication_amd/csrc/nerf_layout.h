@@ -91,9 +91,11 @@ constexpr int kF16FragL0 = 0;                    // 8 m x 4 PE k-steps
 constexpr int kF16FragL1 = 32;                   // L1..L4: 8 m x 16
 constexpr int kF16FragL5 = kF16FragL1 + 4 * 128; // 8 m x (4 PE + 16 hidden) = 160
 constexpr int kF16FragL6 = kF16FragL5 + 160;     // L6, L7
-constexpr int kF16FragFeat = kF16FragL6 + 2 * 128;
-constexpr int kF16FragSigma = kF16FragFeat + 128;  // 1 m (row 0) x 16
-constexpr int kF16FragViews = kF16FragSigma + 16;  // 4 m x (16 feature + 2 dir)
+// the sigma head comes BEFORE the feature layer (both read relu(h7)): a density-only pass ends its stream right behind
+// layer 7, and a wave whose 32 points carry no density knows it before the colour branch starts
+constexpr int kF16FragSigma = kF16FragL6 + 2 * 128; // 1 m (row 0) x 16
+constexpr int kF16FragFeat = kF16FragSigma + 16;    // 8 m x 16
+constexpr int kF16FragViews = kF16FragFeat + 128;   // 4 m x (16 feature + 2 dir)
 constexpr int kF16FragRgb = kF16FragViews + 72;    // 1 m (rows 0..2) x 8
 constexpr int kF16Frags = kF16FragRgb + 8;         // 1184 = 37 chunks exactly
 constexpr int kF16Chunks = kF16Frags / kF16ChunkFrags;

@@ -121,10 +121,10 @@ def pack_model_f16(sd, prefix, split=False):
             frags.append(_frag(W5, rows_of(m), lambda j, h, s=s: 63 + act16_feat(s, j, h)))
     for i in (6, 7):
         hidden(g(f"pts_linears.{i}.weight"))
-    hidden(g("feature_linear.weight"))
     Wa = g("alpha_linear.weight")
-    for s in range(16):                                          # sigma head: row 0
+    for s in range(16):                                          # sigma head: row 0 (ahead of the feature layer)
         frags.append(_frag(Wa, [0] + [-1] * 31, lambda j, h, s=s: act16_feat(s, j, h)))
+    hidden(g("feature_linear.weight"))
     Wv = g("views_linears.0.weight")
     for m in range(4):                                           # views: 16 feature + 2 dir k-steps
         for s in range(16):
