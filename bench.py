@@ -302,7 +302,9 @@ def run_config5(pkg, sd, dev, world, rank, steps=2):
         elapsed = tt.item()
     finite = bool(torch.isfinite(rgb).all().item() and torch.isfinite(dep).all().item())
     rays_per_s = n * steps / elapsed
-    # executed FLOP per ray: the coarse launch is density-only (see the headline's config.coarse_pass)
+    # executed FLOP per ray: the coarse launch is density-only (see the headline's config.coarse_pass); the colour branch that
+    # waves without density skip in the fine launch is NOT subtracted here (its share is scene-dependent: the headline's
+    # roofline.fine_tiles_without_density), so this frac over-counts the executed FLOP by up to 17 % x that share
     flop_per_ray = 64 * (FLOP_PER_POINT - FLOP_DENSITY_SKIPPED) + 192 * FLOP_PER_POINT
     return {"workload": "1600x1600 frame = 2560000 rays, 64+128 (coarse pass density-only), fp16 activations + fp32 accumulate (nerf_mlp_f16_kernel)",
             "rays_per_s": round(rays_per_s, 1), "ms_per_frame": round(elapsed / steps * 1e3, 2), "steps": steps, "warmup": 1,
