@@ -302,17 +302,19 @@ def run_config5(pkg, sd, dev, world, rank, steps=2):
         elapsed = tt.item()
     finite = bool(torch.isfinite(rgb).all().item() and torch.isfinite(dep).all().item())
     rays_per_s = n * steps / elapsed
-    # executed FLOP per ray: the coarse launch is density-only (see the headline's config.coarse_pass); the colour branch that
-    # waves without density skip in the fine launch is NOT subtracted here (its share is scene-dependent: the headline's
-    # roofline.fine_tiles_without_density), so this frac over-counts the executed FLOP by up to 17 % x that share
-    flop_per_ray = 64 * (FLOP_PER_POINT - FLOP_DENSITY_SKIPPED) + 192 * FLOP_PER_POINT
+    # executed FLOP per ray: the coarse launch is density-only (see the headline's config.coarse_pass) and waves without
+    # density skip the colour branch in the fine launch: counted from the sigma output of one more pass over this shard
+    st5 = time_stages(pkg, net, ren, o, d, 1, prec=1)
+    dead5, tiles5 = st5["_dead_fine_tiles"], st5["_fine_tiles"]
+    flop_per_ray = 64 * (FLOP_PER_POINT - FLOP_DENSITY_SKIPPED) + 192 * FLOP_PER_POINT - dead5 * 32 * FLOP_DENSITY_SKIPPED / max(1, hi - lo)
     return {"workload": "1600x1600 frame = 2560000 rays, 64+128 (coarse pass density-only), fp16 activations + fp32 accumulate (nerf_mlp_f16_kernel)",
             "rays_per_s": round(rays_per_s, 1), "ms_per_frame": round(elapsed / steps * 1e3, 2), "steps": steps, "warmup": 1,
             "n_gpus": world, "finite": finite,
             "roofline": {"bound": "mfma", "achieved": round(rays_per_s * flop_per_ray / 1e12, 1),
                          "peak": PEAK_F16_MFMA * world / 1e12, "unit": "TFLOP/s",
                          "frac": round(rays_per_s * flop_per_ray / (PEAK_F16_MFMA * world), 4),
-                         "flop_per_ray_executed": flop_per_ray, "flop_per_ray_reference_algorithm": POINTS_PER_RAY * FLOP_PER_POINT}}
+                         "flop_per_ray_executed": flop_per_ray, "flop_per_ray_reference_algorithm": POINTS_PER_RAY * FLOP_PER_POINT,
+                         "fine_tiles_without_density": {"tiles": dead5, "of": tiles5}}}
 
 
 def cpu_baseline_config1(sd):
