@@ -356,7 +356,7 @@ def main():
     ap.add_argument("--compare-full-coarse", "--compare-full-network", dest="compare_full_coarse", action="store_true",
                     help="also time the FULL coarse and fine networks (every colour computed) beside the launches the render makes "
                          "(density-only coarse pass; fine tiles without density stop after the sigma head), and report the frame "
-                         "rate the headline would have with them (profiles/r02_full_network_compare.json)")
+                         "rate the headline would have with them (profiles/r02_full_network_compare_<precision>.json)")
     ap.add_argument("--no-dense-compare", dest="compare_dense", action="store_false",
                     help="--mode train: do not append the six steps with NERF_DEAD_TILE_SKIP=0 that give "
                          "ms_per_step_without_dead_tile_skip (profiles/collect.sh: keeps the rocprofv3 rows of the timed steps clean)")
@@ -510,7 +510,7 @@ def main():
                                           "N_importance > 0 (volume_renderer.py:335), rgb/depth are bit-identical to running "
                                           "the full coarse network; fp32 fine launch: 32-sample tiles without a single sigma > 0 stop after the sigma head "
                                           "too (weight exactly 0 in compositing).  --compare-full-network times the full networks beside "
-                                          "them: profiles/r02_full_network_compare.json"
+                                          "them: profiles/r02_full_network_compare_<precision>.json"
                                           ),
                           "rays_per_step": n, "parallelism": f"ray-tile shard x{world} (each rank generates and renders only "
                                                              "its tile) + 1 all_gather",
