@@ -465,8 +465,7 @@ def main():
     coarse_flop_per_point = FLOP_PER_POINT - FLOP_DENSITY_SKIPPED
     dead_tiles, fine_tiles = stages.pop("_dead_fine_tiles"), stages.pop("_fine_tiles")
     flop_frame_executed = (hi - lo) * (64 * coarse_flop_per_point + 192 * FLOP_PER_POINT)
-    if prec in (0, 1):   # the fp32 and fp16 kernels skip the colour branch of dead tiles
-        flop_frame_executed -= dead_tiles * 32 * FLOP_DENSITY_SKIPPED
+    flop_frame_executed -= dead_tiles * 32 * FLOP_DENSITY_SKIPPED        # dead tiles skip the colour branch (every precision)
     flop_frame_reference = (hi - lo) * POINTS_PER_RAY * FLOP_PER_POINT
     flop_per_launch = flop_frame_executed / 2.0
     achieved = flop_per_launch / (mlp_ms_per_launch * 1e-3) / 1e12

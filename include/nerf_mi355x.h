@@ -96,8 +96,8 @@ int32_t nerf_mlp_forward_rays_density(const float* rays_o, const float* rays_d, 
  * sigma column is bit for bit nerf_mlp_forward_rays'; the rgb columns are too, EXCEPT that they may be 0 for points whose
  * sigma is <= 0 -- compositing gives those samples alpha = 1 - exp(-relu(sigma) delta) = 0, hence weight 0, and multiplies their
  * colour by exactly zero (volume_renderer.py:67-96, :414-437), so rgb and depth out of nerf_composite are bit-identical either
- * way.  NERF_PREC_F32 / NERF_PREC_F16: a 32-point tile (32 consecutive samples) without a single sigma > 0 skips the colour
- * branch (17 % of its FLOP); how many tiles do is scene-dependent.  NERF_PREC_F32X: identical to nerf_mlp_forward_rays. */
+ * way.  A 32-point tile (32 consecutive samples) without a single sigma > 0 skips the colour branch (17 % of its FLOP), in
+ * every precision; how many tiles do is scene-dependent. */
 int32_t nerf_mlp_forward_rays_for_compositing(const float* rays_o, const float* rays_d, const float* tvals,
                                               int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
                                               const void* packed, float* raw, int32_t precision, void* stream);

@@ -991,6 +991,7 @@ int launch_mlp(const MlpArgs& a, bool ray_mode, int precision, hipStream_t st) {
     const long long n_tiles = (a.n_points + kXTilePts - 1) / kXTilePts;
     const unsigned blocks = (unsigned)(n_tiles < num_cus() ? n_tiles : num_cus());
     if (ray_mode && a.density_only) hipLaunchKernelGGL((nerf_mlp_f32x_kernel<true, false, true>), dim3(blocks), dim3(kXThreads), 0, st, a);
+    else if (ray_mode && a.skip_dead_colour && NERF_F32_DEAD_SKIP) hipLaunchKernelGGL((nerf_mlp_f32x_kernel<true, false, false, true>), dim3(blocks), dim3(kXThreads), 0, st, a);
     else if (ray_mode) hipLaunchKernelGGL(nerf_mlp_f32x_kernel<true>, dim3(blocks), dim3(kXThreads), 0, st, a);
     else hipLaunchKernelGGL(nerf_mlp_f32x_kernel<false>, dim3(blocks), dim3(kXThreads), 0, st, a);
     return check_launch("nerf_mlp_f32x_kernel");

@@ -212,8 +212,7 @@ def test_density_only_forward_is_the_full_forwards_sigma(amd, synthetic_sd, gold
 def test_compositing_forward_drops_only_colours_that_are_multiplied_by_zero(amd, golden, family_sd, family, precision):
     """nerf_mlp_forward_rays_for_compositing (the fine pass of nerf_render_forward) vs nerf_mlp_forward_rays on the reference's
     own merged depths of every scene family: sigma bit-identical everywhere; rgb bit-identical wherever it is not zeroed; a
-    zeroed colour only at points with sigma <= 0 (weight exactly 0) and, for fp32 / fp16, exactly in the 32-sample tiles without a
-    single sigma > 0; nerf_composite of the two raw buffers bit-identical.  The families cover 0 % ... 86 % dead tiles."""
+    zeroed colour only at points with sigma <= 0 (weight exactly 0), exactly in the 32-sample tiles without a single sigma > 0; nerf_composite of the two raw buffers bit-identical.  The families cover 0 % ... 86 % dead tiles."""
     lib, L = amd._lib.load(), amd._lib
     g = golden(f"render_family_{family}.npz")
     net = amd.Network(); net.load_state_dict(family_sd(family)); net = net.cuda().eval(); net.precision = precision
@@ -234,15 +233,13 @@ def test_compositing_forward_drops_only_colours_that_are_multiplied_by_zero(amd,
     assert torch.all(comp[..., :3][dropped] == 0)
     assert torch.all(full[..., 3][dropped] <= 0)
     dead_tiles = (full[..., 3] <= 0).reshape(n, 6, 32).all(-1)
-    if precision in ("f32", "f16"):                                 # (fp16: per wave = the same 32 consecutive samples)
-        live_pts = ~dead_tiles[:, :, None].expand(n, 6, 32).reshape(n, 192)
-        assert not dropped[live_pts].any()                          # every tile with a live point ran in full
-        # (a dead tile whose full colours happen to be exactly 0 would not show up in `dropped`: only an upper bound here)
-        assert dropped.reshape(n, 6, 32).any(-1).sum() <= dead_tiles.sum()
-        if family in ("sharp", "trained", "base"):
-            assert dropped.any(), "fixture lost its dead tiles"
-    else:
-        assert not dropped.any()                                    # these kernels run every tile in full
+    # every precision decides per 32 consecutive samples (fp32: a one-wave workgroup tile; fp16 / split-fp16: one wave of the tile)
+    live_pts = ~dead_tiles[:, :, None].expand(n, 6, 32).reshape(n, 192)
+    assert not dropped[live_pts].any()                              # every tile with a live point ran in full
+    # (a dead tile whose full colours happen to be exactly 0 would not show up in `dropped`: only an upper bound here)
+    assert dropped.reshape(n, 6, 32).any(-1).sum() <= dead_tiles.sum()
+    if family in ("sharp", "trained", "base"):
+        assert dropped.any(), "fixture lost its dead tiles"
     outs = []
     for raw in (full, comp):
         rgb, dep = torch.empty(n, 3, device="cuda"), torch.empty(n, device="cuda")
