@@ -55,9 +55,20 @@ def camera_pose_40():
     return c2w
 
 
-def load_weights():
-    ck = torch.load(os.path.join(REPO, "tests", "golden", "synthetic_ckpt.pth"), weights_only=True)
+def load_weights(name="synthetic_ckpt.pth"):
+    ck = torch.load(os.path.join(REPO, "tests", "golden", name), weights_only=True)
     return ck["net"]
+
+
+def sharp_teacher(sd):
+    """The "sharp" scene family of the parity tests (oracle.WEIGHT_FAMILIES, restated here: the product side never imports the
+    oracle): density head of the synthetic checkpoint x 7.5, bias x 7.5 - 30 -- hard surfaces, ~5 % of the samples occupied.
+    tests/golden/trained_ckpt.pth is a network this build trained against renders of exactly this scene."""
+    out = {k: v.clone() for k, v in sd.items()}
+    for m in ("model", "model_fine"):
+        out[f"{m}.alpha_linear.weight"] = out[f"{m}.alpha_linear.weight"] * 7.5
+        out[f"{m}.alpha_linear.bias"] = out[f"{m}.alpha_linear.bias"] * 7.5 - 30.0
+    return out
 
 
 def time_stages(pkg, net, ren, o, d, steps, prec=0, full_coarse=False):
@@ -120,7 +131,8 @@ def host_cores():
             n = min(n, max(1, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
-    return max(1, min(n, 16))
+    cap = int(os.environ.get("NERF_BENCH_CPU_THREADS", "16"))      # a 1-GPU box's CPU share is 16 threads (the host shows 256)
+    return max(1, min(n, cap))
 
 
 def cpu_baseline(sd, n_sample, budget_s=20.0):
@@ -151,37 +163,44 @@ def cpu_baseline(sd, n_sample, budget_s=20.0):
 
 
 def run_training(pkg, sd, dev, precision, steps, warmup, world, rank, compare_dense=True):
-    """BASELINE config 3: 4096 rays per iteration per GPU (4 x 1024 random pixels), forward with activation save,
-    backward through the adjoint kernels, [one gradient all-reduce], clip 40, Adam lr 5e-4 -- the reference's
-    intended step.  One "step" = one iteration.  Returns the measured block (max over ranks)."""
+    """BASELINE config 3: 4096 rays per iteration per GPU, forward with activation save, backward through the adjoint kernels,
+    [one gradient all-reduce], clip 40, Adam lr 5e-4 -- the reference's intended step.  One "step" = one iteration.
+    A representative training state (round-2 VERDICT item 1d): the student is tests/golden/trained_ckpt.pth (3000 steps of this
+    very step), the targets are renders of the scene it was trained on (the "sharp" teacher), and every step draws FRESH random
+    pixels (a pool of batches rendered by the teacher before the timed region: in the reference the targets are dataset images).
+    `sd` is the synthetic checkpoint (the teacher's base).  Returns the measured block (max over ranks)."""
     from nerf_replication_amd.training import train_step, FusedAdam
     n_rays = 4096
     net = pkg.Network()
-    net.load_state_dict(sd, strict=True)
+    net.load_state_dict(load_weights("trained_ckpt.pth"), strict=True)
     net = net.to(dev).train()
     net.precision = precision
     ren = pkg.Renderer(net)
-    ids = torch.randperm(H * W, generator=torch.Generator().manual_seed(rank))[:n_rays].to(dev)
-    o, d = pkg.generate_rays(camera_pose_40(), H, W, 0.6911112070083618, dev, pixel_ids=ids)
-    # targets: the synthetic scene's own render of these rays + 10 % uniform noise.  (Targets of pure noise, the earlier
-    # choice, make the optimiser collapse the density field within a few steps -- 87 % of the backward tiles then carry no
-    # gradient at all and the step time measures the collapse, not the scene the headline renders.)
+    n_dense = 5 if compare_dense and os.environ.get("NERF_DEAD_TILE_SKIP") != "0" else 0
+    n_batches = warmup + steps + (n_dense + 1 if n_dense else 0)
+    teacher = pkg.Network()
+    teacher.load_state_dict(sharp_teacher(sd), strict=True)
+    teacher = teacher.to(dev).eval()
+    t_ren = pkg.Renderer(teacher)
+    gen = torch.Generator().manual_seed(1000 + rank)
+    ids = torch.stack([torch.randperm(H * W, generator=gen)[:n_rays] for _ in range(n_batches)]).to(dev)
+    pool_o, pool_d = pkg.generate_rays(camera_pose_40(), H, W, 0.6911112070083618, dev, pixel_ids=ids.reshape(-1))
     with torch.no_grad():
-        net.eval()
-        rgb0, _ = ren.render({"rays_o": o[None], "rays_d": d[None]})
-        net.train()
-    noise = torch.rand(n_rays, 3, generator=torch.Generator().manual_seed(1)).to(dev) - 0.5
-    colors = (rgb0.reshape(n_rays, 3).float() + 0.1 * noise).clamp_(0.0, 1.0).contiguous()
+        pool_c, _ = t_ren.render({"rays_o": pool_o[None], "rays_d": pool_d[None]})
+    pool_o, pool_d = pool_o.reshape(n_batches, n_rays, 3), pool_d.reshape(n_batches, n_rays, 3)
+    pool_c = pool_c.reshape(n_batches, n_rays, 3).float().contiguous()
+    del teacher, t_ren
+    batch = lambda i: (pool_o[i], pool_d[i], pool_c[i])
     opt = FusedAdam(net.parameters(), lr=5e-4, eps=1e-8, clip_value=40.0)      # one launch: clip 40 + Adam
-    for _ in range(warmup):
-        train_step(ren, opt, o, d, colors)
+    for i in range(warmup):
+        first_loss = train_step(ren, opt, *batch(i))
     ren.live_tile_stats = []                 # per timed step: live / all 32-point tiles of the two backward passes (device ints)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = train_step(ren, opt, o, d, colors)
+    for i in range(steps):
+        loss = train_step(ren, opt, *batch(warmup + i))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -191,7 +210,7 @@ def run_training(pkg, sd, dev, precision, steps, warmup, world, rank, compare_de
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     ms = elapsed / steps * 1e3
-    # live-tile fractions of the timed steps (fp32 backward drops tiles whose incoming gradient is zero throughout: exact)
+    # live-tile fractions of the timed steps (the backward drops tiles whose incoming gradient is zero throughout: exact)
     stats, ren.live_tile_stats = ren.live_tile_stats, None
     live_f = live_c = 1.0
     if stats:
@@ -200,33 +219,33 @@ def run_training(pkg, sd, dev, precision, steps, warmup, world, rank, compare_de
             live_f = sum(cf) / (len(cf) * stats[0][1]); live_c = sum(cc) / (len(cc) * stats[0][3])
     # the same step with the skipping switched off (every tile computed), a few steps right after the timed ones
     ms_dense = None
-    if compare_dense and os.environ.get("NERF_DEAD_TILE_SKIP") != "0":
+    if n_dense:
         os.environ["NERF_DEAD_TILE_SKIP"] = "0"
         try:
-            train_step(ren, opt, o, d, colors)
+            train_step(ren, opt, *batch(warmup + steps))
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(5):
-                train_step(ren, opt, o, d, colors)
+            for i in range(n_dense):
+                train_step(ren, opt, *batch(warmup + steps + 1 + i))
             torch.cuda.synchronize()
-            ms_dense = (time.perf_counter() - t1) / 5 * 1e3
+            ms_dense = (time.perf_counter() - t1) / n_dense * 1e3
         finally:
             del os.environ["NERF_DEAD_TILE_SKIP"]
-    # fwd + data-grad + weight-grad, per GPU.  The fp32 chain runs the COARSE pass density-only (its colour branch --
-    # feature 256x256, views 283x128, rgb 128x3 = 204 288 FLOP per point -- is computed by the reference but never used,
-    # SURVEY F6/F10, and skipped here): the roofline counts the FLOP actually executed, not the reference's
+    # FLOP per step and GPU.  Reference algorithm: forward + data gradient + weight gradient = 3 x 256 points x
+    # 1 186 816 per ray.  Executed: the COARSE pass is density-only in all three thirds of the fp32 chain (its colour branch --
+    # feature 256x256, views 283x128, rgb 128x3 = 204 288 FLOP per point -- is computed by the reference but never used, SURVEY
+    # F6/F10); f32x still runs the coarse colour branch in its two chain kernels (on zeros) and skips only the weight-gradient jobs
     flop_ref = n_rays * POINTS_PER_RAY * FLOP_PER_POINT * 3.0
-    # (f32x: its chain kernels still run the coarse colour branch -- on zeros --, only the three weight-gradient jobs are skipped)
-    skipped = n_rays * 64 * 204288 * (3.0 if precision == "f32" else 1.0)
-    flop = flop_ref - skipped
+    flop_dense = flop_ref - n_rays * 64 * FLOP_DENSITY_SKIPPED * (3.0 if precision == "f32" else 1.0)
+    fwd_f = n_rays * 192 * FLOP_PER_POINT
     if precision == "f32x":      # forward in full (coarse colour branch included); the two backward thirds only on live tiles
-        fwd_f, fwd_c = n_rays * 192 * FLOP_PER_POINT, n_rays * 64 * FLOP_PER_POINT
-        flop = (fwd_f + fwd_c) + (fwd_f * live_f + fwd_c * live_c) + (fwd_f * live_f + n_rays * 64 * (FLOP_PER_POINT - 204288) * live_c)
-    if precision == "f32":       # forward in full; the two backward thirds only on live tiles
-        fwd_f, fwd_c = n_rays * 192 * FLOP_PER_POINT, n_rays * 64 * (FLOP_PER_POINT - 204288)
+        fwd_c = n_rays * 64 * FLOP_PER_POINT
+        flop = (fwd_f + fwd_c) + (fwd_f * live_f + fwd_c * live_c) + (fwd_f * live_f + n_rays * 64 * (FLOP_PER_POINT - FLOP_DENSITY_SKIPPED) * live_c)
+    else:                        # forward in full; the two backward thirds only on live tiles
+        fwd_c = n_rays * 64 * (FLOP_PER_POINT - FLOP_DENSITY_SKIPPED)
         # (the fine forward also drops the colour branch of its density-free tiles: counted as every backward-dead tile,
         # which can only under-count what was executed)
-        flop = (fwd_f - (1.0 - live_f) * n_rays * 192 * 204288 + fwd_c) + 2.0 * (fwd_f * live_f + fwd_c * live_c)
+        flop = (fwd_f - (1.0 - live_f) * n_rays * 192 * FLOP_DENSITY_SKIPPED + fwd_c) + 2.0 * (fwd_f * live_f + fwd_c * live_c)
     # f32x: three fp16 (or six bf16) MFMAs per algorithmic MAC -> ceiling = a third of the fp16 peak
     peak = PEAK_F32_MFMA if precision == "f32" else PEAK_F16_MFMA / 3.0
     traffic = None
@@ -236,15 +255,23 @@ def run_training(pkg, sd, dev, precision, steps, warmup, world, rank, compare_de
         pass
     return {"rays_per_s": round(n_rays * world / (ms * 1e-3), 1), "ms_per_step": round(ms, 3), "steps": steps,
             "warmup": warmup, "rays_per_iter_per_gpu": n_rays,
+            "state": "student tests/golden/trained_ckpt.pth, targets = renders of the 'sharp' teacher scene, fresh random 4096 pixels per step",
             "roofline": {"bound": "mfma", "achieved": round(flop / (ms * 1e-3) / 1e12, 2), "peak": round(peak / 1e12, 1),
                          "unit": "TFLOP/s", "frac": round(flop / (ms * 1e-3) / peak, 4), "traffic": traffic,
-                         "flop_per_step_executed": flop, "flop_per_step_reference_algorithm": flop_ref},
+                         "flop_per_step_executed": flop, "flop_per_step_reference_algorithm": flop_ref,
+                         # scene-independent: every tile computed (NERF_DEAD_TILE_SKIP=0; the coarse pass still density-only)
+                         "ms_per_step_every_tile": None if ms_dense is None else round(ms_dense, 3),
+                         "rays_per_s_every_tile": None if ms_dense is None else round(n_rays * world / (ms_dense * 1e-3), 1),
+                         "frac_every_tile": None if ms_dense is None else round(flop_dense / (ms_dense * 1e-3) / peak, 4),
+                         # SURVEY 8(d)'s definition: the REFERENCE algorithm's FLOP over the measured time; exceeds what the kernels
+                         # do (and may exceed 1) by exactly the work skipped: dead tiles and the coarse colour branch
+                         "frac_reference_algorithm": round(flop_ref / (ms * 1e-3) / peak, 4)},
             "live_tile_fraction": {"fine": round(live_f, 4), "coarse": round(live_c, 4),
-                                   "note": "32-point tiles with a non-zero incoming gradient, mean over the timed steps; the fp32 "
+                                   "note": "32-point tiles with a non-zero incoming gradient, mean over the timed steps; the "
                                            "backward skips the others (exact: d loss / d raw is zero wherever relu(sigma) = 0); "
                                            "scene- and step-dependent"},
             "ms_per_step_without_dead_tile_skip": None if ms_dense is None else round(ms_dense, 3),
-            "final_loss": round(loss.item(), 6)}
+            "first_loss": round(first_loss.item(), 6) if warmup else None, "final_loss": round(loss.item(), 6)}
 
 
 TRAIN_DTYPE = {"f32": "f32", "f32x": "f32x (split-fp16 fwd/bwd chains, bf16x3 weight gradients for the 256x256 layers, "
@@ -261,9 +288,9 @@ def train_bench(pkg, sd, dev, args, world, rank):
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": TRAIN_DTYPE[precision], "data": "synthetic",
-                          "config": {"workload": "BASELINE.json configs[2]: 4096 rays/iter per GPU, MSE on fine RGB (targets: the synthetic "
-                                                 "scene's own render + 10 % noise), clip 40, Adam 5e-4; data parallel: one 4.77 MB "
-                                                 "gradient all-reduce per step"},
+                          "config": {"workload": "BASELINE.json configs[2]: 4096 rays/iter per GPU, MSE on fine RGB (student: the trained "
+                                                 "checkpoint; targets: renders of its teacher scene; fresh random pixels per step), "
+                                                 "clip 40, Adam 5e-4; data parallel: one 4.77 MB gradient all-reduce per step"},
                           "roofline": r["roofline"], "final_loss": r["final_loss"],
                           "live_tile_fraction": r["live_tile_fraction"],
                           "ms_per_step_without_dead_tile_skip": r["ms_per_step_without_dead_tile_skip"]}), flush=True)
@@ -304,9 +331,11 @@ def run_config5(pkg, sd, dev, world, rank, steps=2):
     rays_per_s = n * steps / elapsed
     # executed FLOP per ray: the coarse launch is density-only (see the headline's config.coarse_pass) and waves without
     # density skip the colour branch in the fine launch: counted from the sigma output of one more pass over this shard
-    st5 = time_stages(pkg, net, ren, o, d, 1, prec=1)
+    st5 = time_stages(pkg, net, ren, o, d, 1, prec=1, full_coarse=True)
     dead5, tiles5 = st5["_dead_fine_tiles"], st5["_fine_tiles"]
     flop_per_ray = 64 * (FLOP_PER_POINT - FLOP_DENSITY_SKIPPED) + 192 * FLOP_PER_POINT - dead5 * 32 * FLOP_DENSITY_SKIPPED / max(1, hi - lo)
+    ms5 = elapsed / steps * 1e3
+    full5 = n / ((ms5 + st5["mlp_coarse_full_network"] - st5["mlp_coarse"] + st5["mlp_fine_full_network"] - st5["mlp_fine"]) * 1e-3)
     return {"workload": "1600x1600 frame = 2560000 rays, 64+128 (coarse pass density-only), fp16 activations + fp32 accumulate (nerf_mlp_f16_kernel)",
             "rays_per_s": round(rays_per_s, 1), "ms_per_frame": round(elapsed / steps * 1e3, 2), "steps": steps, "warmup": 1,
             "n_gpus": world, "finite": finite,
@@ -314,6 +343,9 @@ def run_config5(pkg, sd, dev, world, rank, steps=2):
                          "peak": PEAK_F16_MFMA * world / 1e12, "unit": "TFLOP/s",
                          "frac": round(rays_per_s * flop_per_ray / (PEAK_F16_MFMA * world), 4),
                          "flop_per_ray_executed": flop_per_ray, "flop_per_ray_reference_algorithm": POINTS_PER_RAY * FLOP_PER_POINT,
+                         "rays_per_s_full_network": round(full5, 1),
+                         "frac_full_network": round(full5 * POINTS_PER_RAY * FLOP_PER_POINT / (PEAK_F16_MFMA * world), 4),
+                         "frac_reference_algorithm": round(rays_per_s * POINTS_PER_RAY * FLOP_PER_POINT / (PEAK_F16_MFMA * world), 4),
                          "fine_tiles_without_density": {"tiles": dead5, "of": tiles5}}}
 
 
@@ -353,10 +385,12 @@ def main():
                     help="the reference's optional ESS/ERT masked fine pass (volume_renderer.py:132-244, off in lego.yaml): "
                          "fine samples the coarse pass marks empty or occluded skip the MLP; a different image, reported "
                          "as its own metric")
-    ap.add_argument("--compare-full-coarse", "--compare-full-network", dest="compare_full_coarse", action="store_true",
-                    help="also time the FULL coarse and fine networks (every colour computed) beside the launches the render makes "
-                         "(density-only coarse pass; fine tiles without density stop after the sigma head), and report the frame "
-                         "rate the headline would have with them (profiles/r02_full_network_compare_<precision>.json)")
+    ap.add_argument("--compare-full-coarse", "--compare-full-network", dest="compare_full_coarse", action="store_true", default=True,
+                    help="(default) also time the FULL coarse and fine networks (every colour computed) beside the launches the render "
+                         "makes (density-only coarse pass; fine tiles without density stop after the sigma head), and report the frame "
+                         "rate the headline would have with them: roofline.rays_per_s_full_network / frac_full_network")
+    ap.add_argument("--no-full-network-compare", dest="compare_full_coarse", action="store_false",
+                    help="skip those extra launches (profiles/collect.sh: keeps the profiled launch count minimal)")
     ap.add_argument("--no-dense-compare", dest="compare_dense", action="store_false",
                     help="--mode train: do not append the six steps with NERF_DEAD_TILE_SKIP=0 that give "
                          "ms_per_step_without_dead_tile_skip (profiles/collect.sh: keeps the rocprofv3 rows of the timed steps clean)")
@@ -383,7 +417,15 @@ def main():
     backend = os.environ.get("NERF_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # NERF_BENCH_FORCE_DIST=1: a one-rank run that still builds the process group and makes every collective an N-rank run makes
+    # (RCCL on the one GPU of a test box; nerf_replication_amd.dist honours NERF_DIST_FORCE_COLLECTIVE)
+    force_dist = world == 1 and os.environ.get("NERF_BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ["NERF_DIST_FORCE_COLLECTIVE"] = "1"
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -403,7 +445,7 @@ def main():
     sd = load_weights()
     if args.mode == "train":
         train_bench(pkg, sd, dev, args, world, rank)
-        if world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
     net = pkg.Network()
@@ -457,6 +499,8 @@ def main():
         print(f"[bench] {args.steps} steps: {ms_per_step:.1f} ms/step, {value:.0f} rays/s", file=sys.stderr, flush=True)
 
     # dominant-kernel roofline on this rank's shard (HIP events on the launch stream)
+    # (the full networks -- every colour computed -- are timed beside the launches the render makes: separate template instances,
+    #  so their launches land in rows of their own in `rocprofv3 --stats`; --no-full-network-compare drops them)
     stages = time_stages(pkg, net, ren, o, d, max(1, min(args.steps, 3)), prec, full_coarse=args.compare_full_coarse)
     mlp_ms_per_launch = (stages["mlp_coarse"] + stages["mlp_fine"]) / 2.0
     # FLOP actually executed: the coarse launch stops after the sigma head (feature_linear 256x256, views_linears.0
@@ -484,15 +528,24 @@ def main():
                                                "note": "32-sample tiles whose sigma is <= 0 throughout: weight exactly 0 in compositing; "
                                                        "the fp32 fine launch stops them after the sigma head (scene-dependent)"},
                 "stage_ms": {k: round(v, 3) for k, v in stages.items()}}
+    # SURVEY 8(d)'s own definition: the REFERENCE algorithm's FLOP (303 824 896 per ray) over the measured time.  It exceeds what the
+    # kernels execute -- and may exceed 1 -- by exactly the skipped dead code (coarse colour branch, colours of density-free tiles)
+    roofline["frac_reference_algorithm"] = round(value * POINTS_PER_RAY * FLOP_PER_POINT / (peak * world), 4)
     if args.compare_full_coarse:
         # the same frame with the coarse network evaluated in full (its colour computed and dropped, as the reference
         # does): derived from the measured step time and the two coarse launches timed side by side
         roofline["rays_per_s_if_coarse_colour_were_computed"] = round(
             n / ((ms_per_step + stages["mlp_coarse_full_network"] - stages["mlp_coarse"]) * 1e-3), 1)
-        # ... and with, in addition, the colours of the zero-density fine tiles computed (every FLOP of the reference's algorithm)
-        roofline["rays_per_s_if_every_colour_were_computed"] = round(
-            n / ((ms_per_step + stages["mlp_coarse_full_network"] - stages["mlp_coarse"]
-                  + stages["mlp_fine_full_network"] - stages["mlp_fine"]) * 1e-3), 1)
+        # ... and with, in addition, the colours of the zero-density fine tiles computed (every FLOP of the reference's algorithm):
+        # the SCENE-INDEPENDENT figures of this line
+        full = n / ((ms_per_step + stages["mlp_coarse_full_network"] - stages["mlp_coarse"]
+                     + stages["mlp_fine_full_network"] - stages["mlp_fine"]) * 1e-3)
+        roofline["rays_per_s_if_every_colour_were_computed"] = round(full, 1)
+        roofline["rays_per_s_full_network"] = round(full, 1)
+        roofline["frac_full_network"] = round(full * POINTS_PER_RAY * FLOP_PER_POINT / (peak * world), 4)
+        # the two full-network launches by themselves (kernel time only, this rank's shard)
+        roofline["frac_full_network_kernels"] = round((hi - lo) * POINTS_PER_RAY * FLOP_PER_POINT /
+                                                      ((stages["mlp_coarse_full_network"] + stages["mlp_fine_full_network"]) * 1e-3) / peak, 4)
 
     out = None
     if rank == 0:
@@ -509,7 +562,7 @@ def main():
                                           "N_importance > 0 (volume_renderer.py:335), rgb/depth are bit-identical to running "
                                           "the full coarse network; fp32 fine launch: 32-sample tiles without a single sigma > 0 stop after the sigma head "
                                           "too (weight exactly 0 in compositing).  --compare-full-network times the full networks beside "
-                                          "them: profiles/r02_full_network_compare_<precision>.json"
+                                          "them on this line: roofline.rays_per_s_full_network / frac_full_network"
                                           ),
                           "rays_per_step": n, "parallelism": f"ray-tile shard x{world} (each rank generates and renders only "
                                                              "its tile) + 1 all_gather",
@@ -517,8 +570,8 @@ def main():
                                                "MLP launches" % ren.weights_threshold} if args.fast_sampling else {})},
                "roofline": roofline,
                # self-check for a scaling record: what torch.distributed really ran, and every rank's own render time
-               "world_size": dist.get_world_size() if world > 1 else 1,
-               "dist_backend": (dist.get_backend() if world > 1 else None),
+               "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+               "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
                "per_rank_compute_ms": [round(x, 3) for x in per_rank_ms]}
         if world == 1 and args.cpu_sample > 0:
             base, (ids, ref_rgb, ref_dep) = cpu_baseline(sd, args.cpu_sample)
@@ -590,7 +643,7 @@ def main():
             out.update(extra)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

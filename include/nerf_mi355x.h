@@ -23,7 +23,17 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 1
+/* Version 2 (round 3).  Contracts that changed since version 1 (entry names and signatures did not):
+ *   - the TrainSave / TrainGrad buffers (nerf_train_save_floats / nerf_train_grad_floats) hold pad32(P) rows per region, with the
+ *     fp32 chain's ReLU sign-bit blocks, the live-tile flags / list / count and a "rows skipped" stamp appended;
+ *     nerf_mlp_backward(NERF_PREC_F32) takes its ReLU masks from those sign bits (written by the SAVE forwards only);
+ *   - with dead-tile skipping (default; NERF_DEAD_TILE_SKIP=0 in the environment disables it) the g_z rows of tiles whose incoming
+ *     gradient is zero throughout are left unwritten in `gsave` (point mode zero-fills the g_zv region, which
+ *     nerf_viewdirs_backward sums over);
+ *   - nerf_mlp_forward_rays_save_for_compositing may omit the rows of density-free tiles; it stamps the buffer, and a backward pass
+ *     that runs without the live-tile list on such a buffer poisons grads[alpha_linear.bias] with NaN instead of reading them;
+ *   - nerf_composite_backward refuses more than 192 samples per ray. */
+#define NERF_ABI_VERSION 2
 
 enum nerf_status {
   NERF_OK = 0,

@@ -102,7 +102,7 @@ def load():
         for name, (res, args) in _PROTOS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.nerf_abi_version() != 1:
+        if lib.nerf_abi_version() != 2:
             raise NerfLibraryError("libnerf_mi355x.so ABI version mismatch")
         if lib.nerf_build_flags() != 0:
             raise NerfLibraryError(f"{LIB_PATH} is a timing build (nerf_build_flags() = {lib.nerf_build_flags()}): kernels "

@@ -970,6 +970,22 @@ void nerf_viewdirs_bwd_kernel(const float* __restrict__ gzv, long long n_rays, i
   }
 }
 
+// ------------------------------------------------------------------------------------ dead-tile skipping: ONE decision for both passes
+// The SAVE forward for compositing drops the rows of density-free tiles, and the backward pass drops tiles without an incoming
+// gradient: the second is only safe to switch off if the first was off too (a dense backward would read rows that were never
+// written).  Both entry points therefore ask this one helper, and the forward stamps what it did into the save buffer
+// (TrainSave::off_stamp): a dense backward on a buffer stamped "rows skipped" poisons the alpha-bias gradient with NaN instead
+// of silently multiplying garbage by zero (the host cannot read the stamp without a synchronisation the ABI does not make).
+bool dead_tile_list_available(long long P, int precision) {
+  const char* env = getenv("NERF_DEAD_TILE_SKIP");
+  const bool want = !(env && env[0] == '0');
+  return want && (precision == NERF_PREC_F32 || precision == NERF_PREC_F32X) && NERF_WGRAD_ASM && NERF_WGVEC_ASM &&
+         NERF_F32_DEAD_SKIP && P % 32 == 0 && P / 32 <= 0x7fffffffLL;
+}
+__global__ void nerf_check_stamp_kernel(const float* __restrict__ stamp, float* __restrict__ poison) {
+  if (threadIdx.x == 0 && __float_as_int(stamp[0]) != 0) poison[0] = __int_as_float(0x7fc00000);
+}
+
 // ------------------------------------------------------------------------------------ launch helpers
 int num_cus() {
   static int cus = 0;
@@ -1378,10 +1394,7 @@ static int32_t mlp_backward_impl(const BwdArgs& a_in, bool pts_mode, float* cons
   // NERF_DEAD_TILE_SKIP=0 in the environment turns it off (tests compare the two).
   const int* live = nullptr; const int* n_live = nullptr;
   {
-    const char* env = getenv("NERF_DEAD_TILE_SKIP");
-    const bool want = !(env && env[0] == '0');
-    if (want && (precision == NERF_PREC_F32 || precision == NERF_PREC_F32X) && NERF_WGRAD_ASM && NERF_WGVEC_ASM && P % 32 == 0 &&
-        P / 32 <= 0x7fffffffLL) {
+    if (dead_tile_list_available(P, precision)) {
       int* flags = reinterpret_cast<int*>(gsave + TrainGrad::off_flags(P));
       int* lv = reinterpret_cast<int*>(gsave + TrainGrad::off_live(P));
       int* cnt = reinterpret_cast<int*>(gsave + TrainGrad::off_count(P));
@@ -1397,10 +1410,19 @@ static int32_t mlp_backward_impl(const BwdArgs& a_in, bool pts_mode, float* cons
         return fail(NERF_ERR_HIP, "%s", "nerf_mlp_backward: memset failed");
       if (pts_mode && a.g_x && hipMemsetAsync(a.g_x, 0, (size_t)P * 3 * sizeof(float), (hipStream_t)stream) != hipSuccess)
         return fail(NERF_ERR_HIP, "%s", "nerf_mlp_backward: memset failed");
+      // point mode has one more consumer of gsave: nerf_viewdirs_backward sums the g_zv rows of ALL samples of a ray, dead
+      // tiles included -- their rows are the zeros written here (ray mode: nothing reads a dead tile's rows)
+      if (pts_mode && hipMemsetAsync(gsave + TrainGrad::off_gzv(P), 0, (size_t)TrainSave::pad32(P) * 128 * sizeof(float), (hipStream_t)stream) != hipSuccess)
+        return fail(NERF_ERR_HIP, "%s", "nerf_mlp_backward: memset failed");
       live = lv; n_live = cnt;
       a.live_tiles = lv; a.n_live = cnt;
-    } else if (hipMemsetAsync(gsave + TrainGrad::off_count(P), 0xFF, sizeof(int), (hipStream_t)stream) != hipSuccess) {   // count = -1: no list
-      return fail(NERF_ERR_HIP, "%s", "nerf_mlp_backward: memset failed");
+    } else {
+      if (hipMemsetAsync(gsave + TrainGrad::off_count(P), 0xFF, sizeof(int), (hipStream_t)stream) != hipSuccess)   // count = -1: no list
+        return fail(NERF_ERR_HIP, "%s", "nerf_mlp_backward: memset failed");
+      // a dense backward needs every row of `save`: refuse (NaN in the alpha-bias gradient) a buffer whose forward skipped rows
+      hipLaunchKernelGGL(nerf_check_stamp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, save + TrainSave::off_stamp(P), grads[nerf::P_BA]);
+      rc = check_launch("nerf_check_stamp_kernel");
+      if (rc) return rc;
     }
   }
   if (precision == NERF_PREC_F32X) {
@@ -1548,6 +1570,10 @@ static int32_t forward_rays_save_impl(const float* rays_o, const float* rays_d, 
   a.rays_o = rays_o; a.rays_d = rays_d; a.tvals = tvals; a.t_ray_stride = t_ray_stride;
   a.n_points = n_rays * n_samples; a.n_samples = n_samples; a.packed = (const float*)packed; a.raw = raw; a.save = save;
   a.density_only = density_only;
+  // stamp: 1 = the rows of density-free tiles are NOT stored (fp32 chain, for-compositing entry with the list available)
+  const bool rows_skipped = precision == NERF_PREC_F32 && !density_only && skip_dead;
+  if (hipMemsetAsync(save + TrainSave::off_stamp(a.n_points), rows_skipped ? 0x01 : 0x00, 4 * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    return fail(NERF_ERR_HIP, "%s", "nerf_mlp_forward_rays_save: memset failed");
   if (precision == NERF_PREC_F32X) {
     const long long n_tiles = (a.n_points + kXTilePts - 1) / kXTilePts;
     const unsigned blocks = (unsigned)(n_tiles < num_cus() ? n_tiles : num_cus());
@@ -1559,7 +1585,7 @@ static int32_t forward_rays_save_impl(const float* rays_o, const float* rays_d, 
   if (tiles > 0x7fffffffLL) return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_mlp_forward_rays_save: too many points for one launch");
   // barrier-free: one-wave workgroups
   if (density_only) hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, true, true>), dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, a);
-  else if (skip_dead && NERF_F32_DEAD_SKIP) hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, true, false, true>), dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, a);
+  else if (skip_dead) hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, true, false, true>), dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, true>), dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, a);
   return check_launch("nerf_mlp_f32_kernel<save>");
 }
@@ -1572,9 +1598,9 @@ int32_t nerf_mlp_forward_rays_save(const float* rays_o, const float* rays_d, con
 int32_t nerf_mlp_forward_rays_save_for_compositing(const float* rays_o, const float* rays_d, const float* tvals,
                                                    int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
                                                    const void* packed, float* raw, float* save, int32_t precision, void* stream) {
-  // without dead-tile skipping in the backward pass every row must exist: fall back to the full store
-  const char* env = getenv("NERF_DEAD_TILE_SKIP");
-  const int skip = !(env && env[0] == '0') && (n_rays * (int64_t)n_samples) % 32 == 0;
+  // without dead-tile skipping in the backward pass every row must exist: fall back to the full store (the SAME helper decides
+  // for the backward pass, and the buffer is stamped with what was done here)
+  const int skip = n_rays > 0 && n_samples > 0 && dead_tile_list_available(n_rays * (int64_t)n_samples, precision);
   return forward_rays_save_impl(rays_o, rays_d, tvals, t_ray_stride, n_rays, n_samples, packed, raw, save, precision, stream, 0, skip);
 }
 int32_t nerf_mlp_forward_rays_save_density(const float* rays_o, const float* rays_d, const float* tvals,
@@ -1591,6 +1617,8 @@ int32_t nerf_mlp_forward_points_save(const float* pts, const float* viewdirs, in
   MlpArgs a{};
   a.pts = pts; a.viewdirs = viewdirs; a.n_points = n_rays * n_samples; a.n_samples = n_samples;
   a.packed = (const float*)packed; a.raw = raw; a.save = save;
+  if (hipMemsetAsync(save + TrainSave::off_stamp(a.n_points), 0, 4 * sizeof(float), (hipStream_t)stream) != hipSuccess)      // every row stored
+    return fail(NERF_ERR_HIP, "%s", "nerf_mlp_forward_points_save: memset failed");
   if (precision == NERF_PREC_F32X) {
     const long long n_tiles = (a.n_points + kXTilePts - 1) / kXTilePts;
     const unsigned blocks = (unsigned)(n_tiles < num_cus() ? n_tiles : num_cus());

@@ -5,8 +5,16 @@ all_gather of packed [n_local,4] (rgb+depth) per frame over RCCL/xGMI reassemble
 New functionality of the build (the reference has no multi-GPU inference path).
 One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm, "gloo" for CPU tests.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def _force_collective():
+    """NERF_DIST_FORCE_COLLECTIVE=1: take the collective path even in a one-rank group, so that a 1-GPU box can drive the very
+    RCCL calls an N-rank run makes (tests/test_gpu_parity.py::test_rccl_single_rank_collectives); results are unchanged."""
+    return dist.is_initialized() and os.environ.get("NERF_DIST_FORCE_COLLECTIVE") == "1"
 
 
 def shard_bounds(n_rays: int, rank: int, world: int):
@@ -36,7 +44,7 @@ def render_shard(renderer, rays_o_local, rays_d_local, n_total, group=None, even
     if timed:
         ev[1].record()
         events.append(ev)
-    if world == 1:
+    if world == 1 and not _force_collective():
         return rgb, depth
     packed = torch.zeros((per, 4), dtype=torch.float32, device=rgb.device)
     packed[: hi - lo, :3] = rgb
@@ -76,7 +84,7 @@ def allreduce_gradients(params, group=None):
     """Data-parallel training (what DDP does for the reference in trainer.py:16-21): average the 48 parameter
     gradients over the ranks with ONE all_reduce of a flat 4.77 MB buffer (2 x 595 844 fp32), then scatter
     the averages back into the .grad tensors.  No-op for a single process."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _force_collective()):
         return
     params = [p for p in params if p.grad is not None]
     if not params:

@@ -129,11 +129,11 @@ class Network(nn.Module):
         -> raw [n,s,4] = (r,g,b,sigma) pre-activation (network.py:199-258).
 
         Differentiable like the reference's: with autograd on and either `inputs.requires_grad` or a `.train()` network
-        whose parameters require grad, the forward runs the SAVE-mode fused kernel and backward() the adjoint HIP
+        whose parameters require grad (or `viewdirs.requires_grad`), the forward runs the SAVE-mode fused kernel and backward() the adjoint HIP
         kernels (nerf_mlp_backward_points, nerf_viewdirs_backward): gradients w.r.t. the 24 tensors of the selected
         sub-model, `inputs` and `viewdirs`."""
         sub = self.model_fine if model == "fine" else self.model
-        if torch.is_grad_enabled() and (inputs.requires_grad or
+        if torch.is_grad_enabled() and (inputs.requires_grad or viewdirs.requires_grad or
                                         (self.training and any(p.requires_grad for p in sub.parameters()))):
             return self._forward_with_grad(inputs, viewdirs, valid_mask, model, sub)
         lib = _lib.load()
@@ -200,15 +200,17 @@ class _MlpFunction(torch.autograd.Function):
                 _lib.check(lib.nerf_mlp_forward_points_save(_lib.ptr(pts), _lib.ptr(dirs), n, s, packed.data_ptr(),
                                                             _lib.ptr(raw), _lib.ptr(save), prec, _lib.stream_of(dev)),
                            "nerf_mlp_forward_points_save")
-        ctx.prec, ctx.shape, ctx.params = prec, (n, s), params
-        ctx.save_for_backward(pts, save, dirs)
+        ctx.prec, ctx.shape = prec, (n, s)
+        # the parameters go through save_for_backward: an in-place update between forward and backward (optimizer.step(),
+        # load_state_dict) then raises autograd's version-counter error instead of pairing new weights with old activations
+        ctx.save_for_backward(pts, save, dirs, *params)
         return raw
 
     @staticmethod
     def backward(ctx, g_raw):
         lib = _lib.load()
-        pts, save, dirs = ctx.saved_tensors
-        params, (n, s), prec = ctx.params, ctx.shape, ctx.prec
+        pts, save, dirs, *params = ctx.saved_tensors
+        (n, s), prec = ctx.shape, ctx.prec
         dev = pts.device
         st = _lib.stream_of(dev)
         flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)

@@ -57,12 +57,12 @@ def synthetic_sd(oracle):
     return {k: ck["net"][k] for k in oracle.state_dict_keys()}
 
 
-PARITY_JSON = os.path.join(REPO, "profiles", "parity_r02.json")
+PARITY_JSON = os.path.join(REPO, "profiles", "parity_r03.json")
 
 
 def parity_record(section, key, stats):
     """Measured parity figures (maxima, quantiles, outlier / moved-sample counts) are KEPT, not just printed
-    (round-1 VERDICT "Weak 2a"): merged into profiles/parity_r02.json; on the GPU box a copy goes to gpurun_out/
+    (round-1 VERDICT "Weak 2a"): merged into profiles/parity_r03.json; on the GPU box a copy goes to gpurun_out/
     (the only directory that travels back), from where it is committed under profiles/."""
     import json
     import shutil
@@ -77,7 +77,7 @@ def parity_record(section, key, stats):
     if torch.cuda.is_available():
         out = os.path.join(REPO, "gpurun_out")
         os.makedirs(out, exist_ok=True)
-        shutil.copyfile(PARITY_JSON, os.path.join(out, "parity_r02.json"))
+        shutil.copyfile(PARITY_JSON, os.path.join(out, "parity_r03.json"))
 
 
 FAMILIES = ("base", "sharp", "white", "trained")

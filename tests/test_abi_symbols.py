@@ -27,7 +27,7 @@ def test_library_builds_loads_and_exports():
     for name in _declared_symbols():
         assert hasattr(lib, name), name
     lib.nerf_abi_version.restype = ctypes.c_int32
-    assert lib.nerf_abi_version() == 1
+    assert lib.nerf_abi_version() == 2
     lib.nerf_packed_model_bytes.restype = ctypes.c_int64
     lib.nerf_packed_model_bytes.argtypes = [ctypes.c_int32]
     # f32: 2 x K=64 layers + 8 x K=256 layers + views (K=288 -> 128) + biases + heads

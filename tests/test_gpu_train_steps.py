@@ -1,0 +1,171 @@
+"""-m gpu: K-step training trajectories of the HIP path against the REAL reference's (round-2 VERDICT item 1).
+
+Fixtures: tests/golden/train_steps_{synthetic,trained}.npz -- K = 5 iterations of trainer.py:53-60 (`loss.backward();
+clip_grad_value_(40); Adam(5e-4, eps 1e-8).step()`, optimizer.py:8-28) on the loss of trainers/nerf.py:27-33, run by the reference
+itself on one fixed 256-ray pinhole batch (oracle/gen_golden.py::training_fixtures).  Compared, for precision f32 and f32x:
+
+  step 1   loss (<= 1e-5 relative: it is the forward), the image, all 48 gradients: the FINE network's tightly, the COARSE
+           network's -- which exist only through the inverse-CDF sampler (volume_renderer.py:255-267) -- ATTRIBUTED:
+           with the HIP path's own coarse densities fed to the CPU oracle's sampler + fine pass under torch autograd, the per-ray
+           sampler adjoint d loss / d sigma_coarse must agree on every well-conditioned ray (smallest used `denom` >= 1e-3, no
+           `denom` within 1 % of the `< 1e-5` switch, no searchsorted comparison within 1e-6 of a tie); the share of the adjoint's
+           energy the excluded rays carry is recorded;
+  step 1   the parameters after the first Adam step (lr * g / (|g| + eps): the sign pattern of the gradient);
+  steps 2..K  loss and share of live coarse samples per step, parameters after step K -- judged against the reference's OWN floor,
+           measured in the same test on the CPU oracle (fp32 vs float64 MLP; tests/test_train_noise_floor.py explains why a flat
+           1e-5 on the loss of step 5 is not meetable by the reference against itself: 5 % between 512- and 65 536-point chunks).
+Everything measured goes to profiles/parity_r03.json, section "training_steps".
+"""
+import json
+import os
+
+import pytest
+import torch
+
+import train_steps_common as T
+from conftest import GOLDEN, parity_record
+
+pytestmark = pytest.mark.gpu
+K = 5
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import nerf_replication_amd as pkg
+    pkg._lib.load()
+    return pkg
+
+
+def _ckpt(oracle, tag):
+    ck = torch.load(os.path.join(GOLDEN, f"{tag}_ckpt.pth"), weights_only=True)["net"]
+    return {k: ck[k] for k in oracle.state_dict_keys()}
+
+
+_FLOOR = {}
+
+
+def _floor(oracle, g, tag):
+    """fp32 vs float64-MLP trajectories of the CPU oracle on the fixture batch (the reference's own rounding floor)."""
+    if tag not in _FLOOR:
+        sd0 = _ckpt(oracle, tag)
+        a32 = T.adam_trajectory(oracle, sd0, g["rays_o"], g["rays_d"], g["target"], K, chunk=1 << 16)
+        a64 = T.adam_trajectory(oracle, sd0, g["rays_o"], g["rays_d"], g["target"], K, mlp_dtype=torch.float64, chunk=1 << 16)
+        keys = oracle.state_dict_keys()
+        rows = T.grad_agreement(a32["grads"][1], a64["grads"][1], keys)
+        _FLOOR[tag] = dict(
+            coarse=T.summarize(rows, "model."), fine=T.summarize(rows, "model_fine."),
+            loss_rel=[max(a, b) for a, b in zip(((a32["loss"] - a64["loss"]).abs() / a64["loss"]).tolist(),
+                                                ((a32["loss"] - g["loss"]).abs() / g["loss"]).tolist())],
+            pdist=max((a32["params"][K][k] - a64["params"][K][k]).abs().max().item() for k in keys),
+            live=(a32["coarse_live_fraction"] - a64["coarse_live_fraction"]).abs().max().item())
+    return _FLOOR[tag]
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32x"])
+@pytest.mark.parametrize("tag", ["trained", "synthetic"])
+def test_training_trajectory_matches_reference(amd, oracle, golden, tag, precision):
+    from nerf_replication_amd.training import FusedAdam, train_step
+    g = golden(f"train_steps_{tag}.npz")
+    keys = oracle.state_dict_keys()
+    sd0 = _ckpt(oracle, tag)
+    net = amd.Network()
+    net.load_state_dict(sd0, strict=True)
+    net = net.cuda().train()
+    net.precision = precision
+    ren = amd.Renderer(net)
+    o, d, target = g["rays_o"].cuda(), g["rays_d"].cuda(), g["target"].cuda()
+    opt = FusedAdam(net.parameters(), lr=5e-4, eps=1e-8, clip_value=40.0)
+    named = dict(net.named_parameters())
+    assert list(named) == keys
+    losses, live, cap = [], [], {}
+    grads1 = params1 = None
+    for step in range(1, K + 1):
+        ren.capture_adjoints = cap if step == 1 else None
+        losses.append(train_step(ren, opt, o, d, target).item())
+        if step == 1:
+            grads1 = {k: named[k].grad.detach().cpu().clone() for k in keys}
+            params1 = {k: named[k].detach().cpu().clone() for k in keys}
+            live.append((cap["raw_coarse"][..., 3] > 0).float().mean().item())
+        else:
+            live.append(float("nan"))
+    ren.capture_adjoints = None
+    paramsK = {k: named[k].detach().cpu().clone() for k in keys}
+    with torch.no_grad():       # coarse densities after K steps (the share of live coarse samples the next step would see)
+        t_c = oracle.stratified_t().unsqueeze(0).expand(256, 64).contiguous()
+        pts_c = oracle.points_on_rays(g["rays_o"], g["rays_d"], t_c).cuda()
+        vd = (g["rays_d"] / g["rays_d"].norm(dim=-1, keepdim=True)).cuda()
+        net.eval()
+        live_after = (net.forward(pts_c, vd, None, model="")[..., 3] > 0).float().mean().item()
+        net.train()
+    floor = _floor(oracle, g, tag)
+
+    # ---- step 1: loss, gradients
+    loss_rel = [abs(a - b) / b for a, b in zip(losses, g["loss"].tolist())]
+    rows = {}
+    for k in keys:
+        ref, got = g["grad1/" + k].double(), T.subsample(grads1[k]).double()
+        scale = ref.abs().max().clamp_min(1e-30)
+        rows[k] = ((got - ref).abs().max() / scale).item() if ref.abs().max() > 0 else got.abs().max().item()
+    fine = max(v for k, v in rows.items() if k.startswith("model_fine."))
+    coarse = max(v for k, v in rows.items() if k.startswith("model."))
+    p1 = max((T.subsample(params1[k]) - g["param1/" + k]).abs().max().item() for k in keys if k.startswith("model_fine."))
+    # sign pattern after one Adam step: share of (subsampled) entries that moved the other way than the reference's
+    def moved_other_way(prefix):
+        bad = tot = 0
+        for k in keys:
+            if not k.startswith(prefix):
+                continue
+            p0 = T.subsample(sd0[k])
+            a, b = T.subsample(params1[k]) - p0, g["param1/" + k] - p0
+            sel = b.abs() > 2.5e-4                    # entries the reference moved by at least half a step
+            bad += int(((a * b) < 0)[sel].sum()); tot += int(sel.sum())
+        return bad / max(1, tot)
+    flips_f, flips_c = moved_other_way("model_fine."), moved_other_way("model.")
+
+    # ---- step 1, attributed: the oracle's sampler + fine pass under autograd ON THE HIP PATH'S coarse densities
+    leaf_sd = {k: sd0[k].detach().clone().requires_grad_(True) for k in keys}
+    r = T.staged_step(oracle, leaf_sd, g["rays_o"], g["rays_d"], g["target"], raw_c_given=cap["raw_coarse"].cpu())
+    ga, gr = cap["g_raw_coarse"].cpu()[..., 3], r["g_raw_c"][..., 3]
+    assert torch.all(cap["g_raw_coarse"][..., :3] == 0)
+    ray_err = (ga - gr).abs().amax(1) / gr.abs().amax(1).clamp_min(1e-30)
+    cond = T.sampler_conditioning(oracle, cap["raw_coarse"].cpu()[..., 3])
+    # (flip_gap ignores the structural ties u[0] = cdf[0] = 0 and u[127] = 1 ~ cdf[62]: they select the same clamped bins either way)
+    n = ga.shape[0]
+    with torch.no_grad():
+        sig = torch.relu(cap["raw_coarse"].cpu()[..., 3])
+        _, parts = oracle.fine_sample(sig, oracle.stratified_t().expand(n, 64), return_parts=True)
+        gap = (parts["cdf"][:, None, 1:-1] - oracle.fine_u()[None, 1:-1, None]).abs().amin(dim=(1, 2))
+    well = (cond["min_live_denom"] >= 1e-3) & (cond["switch_gap"] >= 1e-2) & (gap >= 1e-6)
+    e2 = gr.norm(dim=1) ** 2
+    share_excluded = (e2[~well].sum() / e2.sum().clamp_min(1e-60)).item()
+    err_well = ray_err[well].max().item() if well.any() else 0.0
+    # the coarse-density agreement itself (forward): HIP vs the reference's stored sigma of step 1
+    sig_err = (cap["raw_coarse"].cpu()[..., 3] - g["sigma_coarse_raw"][0]).abs().max().item() / g["sigma_coarse_raw"][0].abs().max().item()
+
+    pK_f = max((T.subsample(paramsK[k]) - g[f"param{K}/" + k]).abs().max().item() for k in keys if k.startswith("model_fine."))
+    pK_c = max((T.subsample(paramsK[k]) - g[f"param{K}/" + k]).abs().max().item() for k in keys if k.startswith("model."))
+    st = dict(loss=losses, loss_reference=g["loss"].tolist(), loss_rel_err=loss_rel, floor_loss_rel=floor["loss_rel"],
+              grad1_fine_worst_rel_err=fine, grad1_coarse_worst_rel_err=coarse,
+              floor_grad1_fine=floor["fine"]["rel_max"], floor_grad1_coarse=floor["coarse"]["rel_max"],
+              param1_fine_max_abs_diff=p1, moved_other_way_fine=flips_f, moved_other_way_coarse=flips_c,
+              sigma_coarse_rel_err=sig_err,
+              ray_adjoint={"rays": n, "well_conditioned": int(well.sum()), "max_err_well_conditioned": err_well,
+                           "q50": torch.quantile(ray_err, 0.5).item(), "q99": torch.quantile(ray_err, 0.99).item(), "max": ray_err.max().item(),
+                           "share_of_energy_in_excluded_rays": share_excluded},
+              paramK_fine_max_abs_diff=pK_f, paramK_coarse_max_abs_diff=pK_c, floor_paramK=floor["pdist"],
+              coarse_live_fraction_step1=live[0], coarse_live_fraction_reference=g["coarse_live_fraction"].tolist(),
+              coarse_live_fraction_after_K=live_after)
+    print(f"training trajectory [{tag}/{precision}]: {json.dumps(st)}")
+    parity_record("training_steps", f"{tag}/{precision}", st)
+
+    assert loss_rel[0] <= 1e-5                                           # the forward
+    assert (cap["raw_coarse"][..., 3].cpu() > 0).float().mean().item() == pytest.approx(g["coarse_live_fraction"][0].item(), abs=2e-4)
+    assert fine <= 1e-3                                                  # smooth in the rounding (floor ~1.5e-4 .. 3.4e-4)
+    assert coarse <= max(3.0 * floor["coarse"]["rel_max"], 2.5e-2)       # the reference's own fp32-vs-fp64 figure: 0.6 % / 3.1 %
+    assert err_well <= 5e-3, (err_well, int(well.sum()))                 # attributed: every well-conditioned ray agrees
+    assert flips_f <= 1e-3
+    # steps 2..K against the floor (3x the reference's own fp32 / fp64 / chunking spread, plus rounding)
+    for s in range(1, K):
+        assert loss_rel[s] <= 3.0 * max(floor["loss_rel"][s], floor["loss_rel"][max(1, s - 1)]) + 1e-4, (s, loss_rel, floor["loss_rel"])
+    assert pK_f <= 3.0 * floor["pdist"] + 1e-3 and pK_c <= 3.0 * floor["pdist"] + 1e-3
+    assert abs(live_after - g["coarse_live_fraction"][K - 1].item()) <= 0.1      # the coarse field is alive (or dead) like the reference's

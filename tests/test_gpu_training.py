@@ -193,7 +193,7 @@ def test_mlp_backward_matches_autograd(amd, net, oracle, synthetic_sd, model, pr
         ref = sd[name].grad
         err = _rel(got, ref)
         worst = max(worst, err)
-        assert err <= 1e-5, (name, err)          # measured <= 1.2e-6 (profiles/parity_r02.json)
+        assert err <= 1e-5, (name, err)          # measured <= 1.2e-6 (profiles/parity_r03.json)
     e_t = _rel(g_t, t_ref.grad)
     print(f"{prefix} [{precision}, |G|~{gscale:g}]: worst parameter-gradient error {worst:.2e}, d/dt error {e_t:.2e}")
     parity_record("gradients", f"mlp_backward_vs_autograd/{prefix}/{precision}/G{gscale:g}",
@@ -291,7 +291,7 @@ def test_training_step_matches_reference_autograd(amd, synthetic_sd, golden, pre
         "per_tensor_rel_err": {k: e for k, e, _ in rows}})
     # the fine model's gradients are smooth in the rounding; the coarse model's go through the inverse-CDF
     # sampler, whose index / `denom < 1e-5` flips make single rays jump (the reference's own discontinuity)
-    # measured (profiles/parity_r02.json): fine 1.2e-4 (f32) / 1.6e-4 (f32x), coarse 5.1e-3 / 8.6e-3 -> ~3x
+    # measured (profiles/parity_r03.json): fine 1.2e-4 (f32) / 1.6e-4 (f32x), coarse 5.1e-3 / 8.6e-3 -> ~3x
     assert fine <= 5e-4 and coarse <= 2.5e-2
     # coarse colour layers receive exactly zero gradient: the coarse RGB is never composited
     for k in ("model.rgb_linear.weight", "model.views_linears.0.weight", "model.feature_linear.weight"):
@@ -656,3 +656,156 @@ def test_per_ray_adjoints_are_independent_of_the_ray_count(amd, golden, n_sub):
     # S > 192 is refused, not silently mis-indexed
     rc = lib.nerf_composite_backward(L.ptr(raw_c), L.ptr(tcd), 0, 1, 193, 1, L.ptr(Gr), None, L.ptr(outs[0]), None, st)
     assert rc != 0 and b"192" in lib.nerf_last_error()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32x"])
+def test_network_forward_viewdirs_gradient_with_dead_tiles(amd, oracle, synthetic_sd, precision):
+    """Round-2 ADVICE (medium): with n*s a multiple of 32 the point-mode backward runs on the live-tile list and leaves the g_zv
+    rows of dead tiles unwritten, while nerf_viewdirs_backward sums g_zv over ALL samples of a ray.  Whole 32-point tiles of the
+    incoming gradient are zero here (the normal case under compositing) and `viewdirs.requires_grad`: d/d viewdirs, d/d inputs and
+    the 24 parameter gradients against the oracle under autograd; on an eval() network too (the gate honours viewdirs)."""
+    gen = torch.Generator().manual_seed(41)
+    n, S = 6, 64                                              # 384 points = 12 tiles, two per ray
+    pts = (torch.rand(n, S, 3, generator=gen) * 2 - 1) * 2.5
+    vd = torch.randn(n, 3, generator=gen) * 0.7
+    G = torch.randn(n, S, 4, generator=gen)
+    tiles = G.view(-1, 32, 4)
+    tiles[[0, 3, 4, 7, 10]] = 0.0                             # ray 0: first half dead; ray 1: second; ray 2: first; ray 3: second; ray 5: first
+    tiles[11] = 0.0
+    tiles[10] = 0.0                                           # ray 5: BOTH tiles dead -> d/d viewdirs of ray 5 is exactly zero
+    net = amd.Network()
+    net.load_state_dict(synthetic_sd, strict=True)
+    net = net.cuda().train()
+    net.precision = precision
+    sd = {k: v.clone().requires_grad_(k.startswith("model_fine.")) for k, v in synthetic_sd.items()}
+    p_ref, vd_ref = pts.clone().requires_grad_(True), vd.clone().requires_grad_(True)
+    (oracle.network_forward(sd, p_ref, vd_ref, "fine") * G).sum().backward()
+    for mode in ("train", "eval"):
+        net.train(mode == "train")
+        net.zero_grad(set_to_none=True)
+        # poison the allocator's free blocks: an uninitialised gsave would show up as NaN / 1e30 in the sums
+        junk = torch.full((n * S * 2432 + 4096,), float("nan"), device="cuda"); del junk
+        p_hip = pts.cuda().requires_grad_(mode == "train")
+        vd_hip = vd.cuda().requires_grad_(True)
+        raw = net(p_hip, vd_hip, None, "fine")
+        assert raw.requires_grad                              # eval(): viewdirs alone switches the autograd path on
+        (raw * G.cuda()).sum().backward()
+        assert torch.isfinite(vd_hip.grad).all()
+        e_d = _rel(vd_hip.grad, vd_ref.grad)
+        assert e_d <= 1e-5, (mode, e_d)
+        assert torch.all(vd_hip.grad[5] == 0) and vd_ref.grad[5].abs().max() == 0
+        if mode == "train":
+            assert _rel(p_hip.grad, p_ref.grad) <= 1e-5
+            assert torch.all(p_hip.grad.view(-1, 32, 3)[[0, 3, 4, 7, 10, 11]] == 0)
+            for name, p in zip([f"model_fine.{k}" for k in oracle.SUBMODEL_KEYS], net.model_fine.ordered_params()):
+                assert _rel(p.grad, sd[name].grad) <= 1e-5, name
+    parity_record("gradients", f"network_forward_viewdirs_dead_tiles/{precision}", {"d_viewdirs_rel_err": e_d})
+
+
+def test_network_forward_detects_parameter_update_between_forward_and_backward(amd, synthetic_sd):
+    """The parameters are saved through save_for_backward: an in-place update between forward and backward raises autograd's
+    version error instead of repacking new weights against activations of the old ones (round-2 ADVICE)."""
+    net = amd.Network()
+    net.load_state_dict(synthetic_sd, strict=True)
+    net = net.cuda().train()
+    pts = torch.rand(2, 32, 3, device="cuda")
+    vd = torch.rand(2, 3, device="cuda")
+    raw = net(pts, vd, None, "")
+    with torch.no_grad():
+        net.model.alpha_linear.bias.add_(1.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        raw.sum().backward()
+
+
+@pytest.mark.parametrize("shape", [(48, 192), (1, 32)])
+@pytest.mark.parametrize("precision", ["f32", "f32x"])
+@pytest.mark.parametrize("dead_frac", [0.6, 1.0])
+def test_point_mode_backward_in_list_mode(amd, net, monkeypatch, dead_frac, precision, shape):
+    """nerf_mlp_forward_points_save / nerf_mlp_backward_points on the live-tile list (round-2 ADVICE: untested paths -- the g_x
+    memset with dead tiles, nerf_mlp_bwd_f32x_kernel<true> taking four list entries per workgroup, nerf_mlp_bwd_f32_kernel<true>
+    with live_tiles) against NERF_DEAD_TILE_SKIP=0: g_pts equal as numbers, the 24 gradients to the rounding of their atomics,
+    and the g_zv region (what nerf_viewdirs_backward reads) zero on dead tiles."""
+    import ctypes
+    lib, L = amd._lib.load(), amd._lib
+    prec = L.PRECISIONS[precision]
+    net.precision = precision
+    gen = torch.Generator().manual_seed(53)
+    n, S = shape
+    P = n * S
+    pts = ((torch.rand(n, S, 3, generator=gen) * 2 - 1) * 2.5).cuda().contiguous()
+    vd = torch.randn(n, 3, generator=gen)
+    vd = (vd / vd.norm(dim=-1, keepdim=True)).cuda().contiguous()
+    G = torch.randn(n, S, 4, generator=gen) * 1e-3
+    tiles = G.view(-1, 32, 4)
+    dead = torch.rand(tiles.shape[0], generator=gen) < dead_frac
+    tiles[dead] = 0.0
+    G = G.cuda().contiguous()
+    params = [p.detach().contiguous() for p in net.model_fine.ordered_params()]
+    arr = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in params])
+    st = L.stream_of(pts.device)
+    pk_b = torch.empty(int(lib.nerf_packed_bwd_bytes(prec)), dtype=torch.uint8, device="cuda")
+    L.check(lib.nerf_pack_model_bwd(arr, pk_b.data_ptr(), prec, st))
+    raw = torch.empty((n, S, 4), device="cuda")
+    save = torch.empty(int(lib.nerf_train_save_floats(P)), device="cuda")
+    L.check(lib.nerf_mlp_forward_points_save(L.ptr(pts), L.ptr(vd), n, S, net.packed("fine").data_ptr(), L.ptr(raw), L.ptr(save), prec, st))
+    out = {}
+    for tag, env in (("skip", "1"), ("dense", "0")):
+        monkeypatch.setenv("NERF_DEAD_TILE_SKIP", env)
+        gsave = torch.full((int(lib.nerf_train_grad_floats(P)),), float("nan"), device="cuda")
+        g_x = torch.full((n, S, 3), float("nan"), device="cuda")
+        grads = [torch.zeros_like(p) for p in params]
+        L.check(lib.nerf_mlp_backward_points(L.ptr(pts), n, S, pk_b.data_ptr(), L.ptr(G), L.ptr(save), L.ptr(gsave), L.ptr(g_x),
+                                             _grad_ptrs(amd, grads), prec, st))
+        torch.cuda.synchronize()
+        out[tag] = (g_x, grads, gsave[:P * 128].view(-1, 32, 128).clone())
+    monkeypatch.delenv("NERF_DEAD_TILE_SKIP")
+    net.precision = "f32"
+    assert torch.isfinite(out["skip"][0]).all() and torch.all(out["skip"][0] == out["dense"][0])
+    assert torch.all(out["skip"][2][dead.cuda()] == 0) and torch.isfinite(out["skip"][2]).all()
+    for gs, gd in zip(out["skip"][1], out["dense"][1]):
+        assert torch.isfinite(gs).all()
+        if bool(dead.all()):
+            assert torch.all(gs == 0) and torch.all(gd == 0)
+        else:
+            assert gd.abs().max() > 0 and _rel(gs, gd.cpu()) <= 1e-5
+
+
+def test_dense_backward_refuses_a_forward_that_skipped_rows(amd, net, family_sd, monkeypatch):
+    """One helper decides about dead-tile skipping for the SAVE forward and for the backward pass, and the forward stamps the save
+    buffer.  If the two are forced apart anyway (environment toggled between the passes), the dense backward does not read the
+    rows that were never written in silence: grads[alpha_linear.bias] comes back NaN."""
+    import ctypes
+    lib, L = amd._lib.load(), amd._lib
+    n, S = 32, 192
+    P = n * S
+    sharp = amd.Network(); sharp.load_state_dict(family_sd("sharp")); sharp = sharp.cuda().eval()
+    gen = torch.Generator().manual_seed(3)
+    o = torch.tensor([0.0, 0.0, 4.0]).expand(n, 3).contiguous().cuda()
+    d = torch.randn(n, 3, generator=gen) * 0.2 + torch.tensor([0.0, 0.0, -1.0])
+    d = (d / d.norm(dim=-1, keepdim=True)).contiguous().cuda()
+    t = torch.sort(torch.rand(n, S, generator=gen) * 4 + 2, dim=-1).values.cuda().contiguous()
+    params = [p.detach().contiguous() for p in sharp.model_fine.ordered_params()]
+    arr = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in params])
+    st = L.stream_of(o.device)
+    pk_b = torch.empty(int(lib.nerf_packed_bwd_bytes(0)), dtype=torch.uint8, device="cuda")
+    L.check(lib.nerf_pack_model_bwd(arr, pk_b.data_ptr(), 0, st))
+    raw = torch.empty((n, S, 4), device="cuda")
+    save = torch.zeros(int(lib.nerf_train_save_floats(P)), device="cuda")
+    monkeypatch.setenv("NERF_DEAD_TILE_SKIP", "1")
+    L.check(lib.nerf_mlp_forward_rays_save_for_compositing(L.ptr(o), L.ptr(d), L.ptr(t), S, n, S, sharp.packed("fine").data_ptr(),
+                                                           L.ptr(raw), L.ptr(save), 0, st))
+    G = torch.zeros(n, S, 4, device="cuda")
+    G[..., 3] = (raw[..., 3] > 0).float() * 1e-3               # the contract: zero wherever sigma <= 0
+    res = {}
+    for env in ("1", "0"):
+        monkeypatch.setenv("NERF_DEAD_TILE_SKIP", env)
+        gsave = torch.zeros(int(lib.nerf_train_grad_floats(P)), device="cuda")
+        g_t = torch.zeros(n, S, device="cuda")
+        grads = [torch.zeros_like(p) for p in params]
+        L.check(lib.nerf_mlp_backward(L.ptr(o), L.ptr(d), L.ptr(t), S, n, S, pk_b.data_ptr(), L.ptr(G), L.ptr(save), L.ptr(gsave),
+                                      L.ptr(g_t), _grad_ptrs(amd, grads), 0, st))
+        torch.cuda.synchronize()
+        res[env] = grads[21]                                  # alpha_linear.bias
+    monkeypatch.delenv("NERF_DEAD_TILE_SKIP")
+    assert torch.isfinite(res["1"]).all()
+    assert torch.isnan(res["0"]).all()

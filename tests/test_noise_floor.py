@@ -11,7 +11,7 @@ deviation of the reference from this better-rounded self IS the floor; the GPU p
 attribute every larger deviation to moved samples, instead of a blanket per-ray maximum.
 
 Numbers asserted below were measured in the build container (torch 2.10 CPU); ranges leave room for another
-CPU's GEMM blocking.  The record goes to profiles/parity_r02.json under "noise_floor" when PARITY_RECORD is set.
+CPU's GEMM blocking.  The record goes to profiles/parity_r03.json under "noise_floor" when PARITY_RECORD is set.
 """
 import json
 import os
