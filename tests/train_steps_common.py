@@ -64,6 +64,64 @@ def staged_step(oracle, sd, o, d, target, mlp_dtype=torch.float32, chunk=None, r
                 t_sorted=depth.detach())
 
 
+def staged_step_fp64(oracle, sd, o, d, target, raw_c_given=None):
+    """The same loss and backward pass evaluated ENTIRELY in float64 on the same fp32 inputs and weights (not the reference's
+    arithmetic: the ground truth both fp32 evaluations -- torch's on the CPU and the HIP kernels' -- are judged against: the
+    adjoint of a nearly converged scene is a sum of large terms of both signs, so fp32 itself is only good to ~1e-2 per ray).
+    `raw_c_given`: use these coarse outputs as the leaf (attribution on identical densities).  Returns g_raw_c [n,64,4] (float64),
+    the bins (below, above) it sampled from, the float64 parameter gradients and the loss."""
+    keys = oracle.state_dict_keys()
+    sd64 = {k: sd[k].detach().double().requires_grad_(True) for k in keys}
+    o, d, target = o.double(), d.double(), target.double()
+    n = o.shape[0]
+    t_c = oracle.stratified_t().double().unsqueeze(0).expand(n, 64).clone()
+    pts_c = oracle.points_on_rays(o, d, t_c)
+    vd = d / torch.norm(d, dim=-1, keepdim=True)
+
+    def mlp(prefix, pts, s):
+        flat = pts.reshape(-1, 3)
+        dflat = vd[:, None].expand(n, s, 3).reshape(-1, 3)
+        emb = torch.cat([oracle.freq_encode(flat, oracle.XYZ_FREQS), oracle.freq_encode(dflat, oracle.DIR_FREQS)], -1)
+        return oracle.nerf_mlp(sd64, prefix, emb).reshape(n, s, 4)
+
+    raw_c = mlp("model", pts_c, 64)
+    leaf = (raw_c if raw_c_given is None else raw_c_given.double()).detach().clone().requires_grad_(True)
+    sigma_c = torch.relu(leaf[..., 3])
+    _, w = oracle.transmittance_weights(sigma_c, t_c)
+    w = w[:, 1:-1] + 1e-5
+    cdf = torch.cumsum(w / torch.sum(w, -1, keepdim=True), -1)
+    cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)
+    u = oracle.fine_u().double().expand(n, 128).contiguous()
+    inds = torch.searchsorted(cdf.detach(), u, right=True)
+    below, above = torch.clamp(inds - 1, 0, 61), torch.clamp(inds, 0, 61)
+    bins = 0.5 * (t_c[:, 1:] + t_c[:, :-1])
+    cb, ca = torch.gather(cdf, 1, below), torch.gather(cdf, 1, above)
+    bb, ba = torch.gather(bins, 1, below), torch.gather(bins, 1, above)
+    denom = ca - cb
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    t_f = bb + (u - cb) / denom * (ba - bb)
+    pts_f = oracle.points_on_rays(o, d, t_f)
+    depth, order = torch.sort(torch.cat([t_c, t_f], 1), dim=-1)
+    pts = torch.gather(torch.cat([pts_c, pts_f], 1), 1, order[..., None].expand(-1, -1, 3))
+    raw_f = mlp("model_fine", pts, 192)
+    rgb, _ = oracle.composite(raw_f, depth, True)
+    loss = torch.nn.functional.mse_loss(rgb, target)
+    loss.backward()
+    g_raw_c = leaf.grad.detach().clone()
+    if raw_c_given is None:
+        raw_c.backward(g_raw_c)
+    grads = {k: (sd64[k].grad.detach().clone() if sd64[k].grad is not None else torch.zeros_like(sd64[k])) for k in keys}
+    return dict(loss=loss.detach(), g_raw_c=g_raw_c, below=below, above=above, grads=grads)
+
+
+def fp32_bins(oracle, raw_c):
+    """(below, above) of the fp32 sampler on these coarse outputs."""
+    with torch.no_grad():
+        n = raw_c.shape[0]
+        _, parts = oracle.fine_sample(torch.relu(raw_c[..., 3]), oracle.stratified_t().expand(n, 64), return_parts=True)
+    return parts["below"], parts["above"]
+
+
 def adam_trajectory(oracle, sd0, o, d, target, K, mlp_dtype=torch.float32, chunk=None, keep_grads=(1,)):
     """K iterations of the reference's step on the CPU oracle (torch.optim.Adam as optimizer.py:8-28 builds it, clip 40)."""
     keys = oracle.state_dict_keys()
