@@ -396,7 +396,7 @@ def main():
                          "ms_per_step_without_dead_tile_skip (profiles/collect.sh: keeps the rocprofv3 rows of the timed steps clean)")
     ap.add_argument("--no-extras", dest="extras", action="store_false",
                     help="skip the training (configs[2]) and 1600x1600 f16 (configs[4]) blocks that follow the headline")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32x"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32x", "f16s"],
                     help="f32 (default, the reference's dtype: exact fp32 MFMA), f16 (BASELINE config 5: fp16 "
                          "activations, fp32 accumulate) or f32x (fp32-accurate: hi/lo split operands, 3 fp16 MFMAs per product)")
     args = ap.parse_args()
@@ -454,7 +454,7 @@ def main():
     net.precision = args.precision
     prec = pkg._lib.PRECISIONS[args.precision]
     # f32x executes 3 fp16 MFMAs per algorithmic MAC: its ceiling in ALGORITHMIC flops is a third of the fp16 peak
-    peak = {0: PEAK_F32_MFMA, 1: PEAK_F16_MFMA, 2: PEAK_F16_MFMA / 3.0}[prec]
+    peak = {0: PEAK_F32_MFMA, 1: PEAK_F16_MFMA, 2: PEAK_F16_MFMA / 3.0, 3: PEAK_F16_MFMA}[prec]
     ren = pkg.Renderer(net)
     ren.fast_sampling = bool(args.fast_sampling)
     # every rank generates ONLY its own tile of the frame's rays, on the device (nerf_generate_rays = the dataset
@@ -552,7 +552,8 @@ def main():
         out = {"metric": f"rays/sec ({H}x{W}, 64+128 samples)" + (", ESS/ERT masked fine pass" if args.fast_sampling else ""), "value": round(value, 1), "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-               "dtype": {0: "f32", 1: "f16 (fp32 accumulate)", 2: "f32 emulated (hi/lo fp16 split x3, fp32 accumulate)"}[prec],
+               "dtype": {0: "f32", 1: "f16 (fp32 accumulate)", 2: "f32 emulated (hi/lo fp16 split x3, fp32 accumulate)",
+                         3: "f16 (fp32 accumulate, 16x16x32 MFMA tiles)"}[prec],
                "data": "synthetic",
                "config": {"workload": f"lego-shaped {H}x{W} frame = {H * W} pinhole rays, 64 coarse + 128 fine "
                                       "hierarchical samples, 8+1-layer W=256 NeRF x2, seeded synthetic weights "

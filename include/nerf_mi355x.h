@@ -47,8 +47,10 @@ enum nerf_precision {
   NERF_PREC_F32 = 0,           /* exact fp32: v_mfma_f32_32x32x2_f32 (the parity path) */
   NERF_PREC_F16 = 1,           /* fp16 activations+weights, fp32 accumulate: v_mfma_f32_32x32x16_f16
                                   (BASELINE config 5; PSNR-level tolerance, not the parity path) */
-  NERF_PREC_F32X = 2           /* fp32-accurate on the fp16 matrix cores: every operand split into hi + 2^-11 lo
+  NERF_PREC_F32X = 2,          /* fp32-accurate on the fp16 matrix cores: every operand split into hi + 2^-11 lo
                                   fp16 parts, 3 MFMAs per product, fp32 accumulate (~2^-22 operand error) */
+  NERF_PREC_F16S = 3           /* NERF_PREC_F16's arithmetic on the other MFMA shape, v_mfma_f32_16x16x32_f16 (same operands and
+                                  accumulation width; only the order of the fp32 partial sums differs); its own packed layout */
 };
 
 /* Renderer constants the reference effectively hard-codes (volume_renderer.py:14-24). */

@@ -15,7 +15,8 @@ N_IMPORTANCE = 128
 PREC_F32 = 0
 PREC_F16 = 1
 PREC_F32X = 2
-PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "f16": PREC_F16, "fp16": PREC_F16, "f32x": PREC_F32X}
+PREC_F16S = 3          # fp16 arithmetic on 16x16x32 MFMA tiles (A/B partner of PREC_F16's 32x32x16 tiles)
+PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "f16": PREC_F16, "fp16": PREC_F16, "f32x": PREC_F32X, "f16s": PREC_F16S}
 
 _c = ctypes
 _F = _c.c_void_p   # device pointers travel as integers (tensor.data_ptr())

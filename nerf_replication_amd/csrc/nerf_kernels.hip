@@ -10,6 +10,7 @@
 #include "nerf_layout.h"
 #include "nerf_mlp_f32.hip.inc"
 #include "nerf_mlp_f16.hip.inc"
+#include "nerf_mlp_f16s.hip.inc"
 #include "nerf_mlp_f32x.hip.inc"
 #include "nerf_wgrad_f32.hip.inc"
 #include "nerf_mlp_bwd_f32.hip.inc"
@@ -183,6 +184,64 @@ __device__ __forceinline__ float f16_stream_value(const PackArgs& a, int F, int 
     if (row < 3) v = a.p[P_WR][row * 128 + 16 * s + cj];
   }
   return v;
+}
+
+// fp32 value of element (fragment F, lane, j) of the f16s fragment stream (16x16x32 tiling, nerf_layout.h "f16s")
+__device__ __forceinline__ float f16s_stream_value(const PackArgs& a, int F, int lane, int j) {
+  using namespace nerf;
+  const int g = lane >> 4, row = lane & 15;
+  const int cj = 16 * (j >> 2) + 4 * g + (j & 3);             // act16s_feat(s,j,g) - 32 s
+  float v = 0.0f;
+  if (F < kF16sFragL1) {                                      // L0: 16 m x 2 PE k-steps
+    const int m = F >> 1, s = F & 1, c = pe16s_xyz_feat(8 * s + j, g);
+    if (c >= 0) v = a.p[P_W0][(16 * m + row) * 63 + c];
+  } else if (F < kF16sFragL5) {                               // L1..L4
+    const int f = F - kF16sFragL1, li = 1 + (f >> 7), m = (f & 127) >> 3, s = f & 7;
+    v = a.p[2 * li][(16 * m + row) * 256 + 32 * s + cj];
+  } else if (F < kF16sFragL6) {                               // L5: 2 PE + 8 hidden k-steps per m
+    const int f = F - kF16sFragL5, m = f / 10, s = f % 10;
+    if (s < 2) { const int c = pe16s_xyz_feat(8 * s + j, g); if (c >= 0) v = a.p[10][(16 * m + row) * 319 + c]; }
+    else v = a.p[10][(16 * m + row) * 319 + 63 + 32 * (s - 2) + cj];
+  } else if (F < kF16sFragSigma) {                            // L6, L7
+    const int f = F - kF16sFragL6, li = 6 + (f >> 7), m = (f & 127) >> 3, s = f & 7;
+    v = a.p[2 * li][(16 * m + row) * 256 + 32 * s + cj];
+  } else if (F < kF16sFragFeat) {                             // sigma head: row 0 only
+    const int s = F - kF16sFragSigma;
+    if (row == 0) v = a.p[P_WA][32 * s + cj];
+  } else if (F < kF16sFragViews) {                            // feature
+    const int f = F - kF16sFragFeat, m = f >> 3, s = f & 7;
+    v = a.p[P_WF][(16 * m + row) * 256 + 32 * s + cj];
+  } else if (F < kF16sFragRgb) {                              // views: 8 feature + 1 dir k-step per m
+    const int f = F - kF16sFragViews, m = f / 9, s = f % 9;
+    if (s < 8) v = a.p[P_WV][(16 * m + row) * 283 + 32 * s + cj];
+    else { const int c = pe16s_dir_feat(j, g); if (c >= 0) v = a.p[P_WV][(16 * m + row) * 283 + 256 + c]; }
+  } else if (F < kF16sFragEnd) {                              // rgb head: rows 0..2
+    const int s = F - kF16sFragRgb;
+    if (row < 3) v = a.p[P_WR][row * 128 + 32 * s + cj];
+  }                                                           // (tail: zero pad fragments)
+  return v;
+}
+
+// f16s stream: const region (fp32 biases in NATURAL order) + A fragments
+__global__ void nerf_pack_f16s_kernel(PackArgs a) {
+  using namespace nerf;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr long long n_const = kF16ConstBytes / 4;
+  constexpr long long n_half = (long long)kF16Frags * 512;
+  if (i < n_const) {
+    float v = 0.0f;
+    if (i < kF16sOffBiasViews) {
+      const int layer = (int)i >> 8, c = (int)i & 255;
+      v = (layer < 8 ? a.p[2 * layer + 1] : a.p[P_BF])[c];
+    } else if (i < kF16sOffHeadBias) v = a.p[P_BV][(int)i - kF16sOffBiasViews];
+    else if (i < kF16sOffHeadBias + 4) { const int rel = (int)i - kF16sOffHeadBias; v = rel < 3 ? a.p[P_BR][rel] : a.p[P_BA][0]; }
+    a.out[i] = v;
+    return;
+  }
+  const long long e = i - n_const;
+  if (e >= n_half) return;
+  const int F = (int)(e >> 9), lane = (int)((e >> 3) & 63), j = (int)(e & 7);
+  reinterpret_cast<_Float16*>(reinterpret_cast<char*>(a.out) + kF16ConstBytes)[e] = (_Float16)f16s_stream_value(a, F, lane, j);
 }
 
 // backward f32x stream: transposed weights as (hi, lo) fragment pairs + w_alpha / w_rgb in the const region
@@ -999,7 +1058,7 @@ int num_cus() {
 }
 
 int launch_mlp(const MlpArgs& a, bool ray_mode, int precision, hipStream_t st) {
-  if (precision != NERF_PREC_F32 && precision != NERF_PREC_F16 && precision != NERF_PREC_F32X)
+  if (precision != NERF_PREC_F32 && precision != NERF_PREC_F16 && precision != NERF_PREC_F32X && precision != NERF_PREC_F16S)
     return fail(NERF_ERR_UNSUPPORTED, "%s", "precision not built");
   if (a.n_points <= 0) return NERF_OK;
   if (a.index && a.n_points > 0x7fffffffLL) return fail(NERF_ERR_INVALID_ARG, "%s", "index mode: point ids are int32");
@@ -1011,6 +1070,15 @@ int launch_mlp(const MlpArgs& a, bool ray_mode, int precision, hipStream_t st) {
     else if (ray_mode) hipLaunchKernelGGL(nerf_mlp_f32x_kernel<true>, dim3(blocks), dim3(kXThreads), 0, st, a);
     else hipLaunchKernelGGL(nerf_mlp_f32x_kernel<false>, dim3(blocks), dim3(kXThreads), 0, st, a);
     return check_launch("nerf_mlp_f32x_kernel");
+  }
+  if (precision == NERF_PREC_F16S) {       // the fp16 path on 16x16x32 MFMA tiles: same workgroup shape and LDS ring
+    const long long n_tiles = (a.n_points + kF16TilePts - 1) / kF16TilePts;
+    const unsigned blocks = (unsigned)(n_tiles < num_cus() ? n_tiles : num_cus());
+    if (ray_mode && a.density_only) hipLaunchKernelGGL((nerf_mlp_f16s_kernel<true, true>), dim3(blocks), dim3(kF16Threads), 0, st, a);
+    else if (ray_mode && a.skip_dead_colour && NERF_F32_DEAD_SKIP) hipLaunchKernelGGL((nerf_mlp_f16s_kernel<true, false, true>), dim3(blocks), dim3(kF16Threads), 0, st, a);
+    else if (ray_mode) hipLaunchKernelGGL(nerf_mlp_f16s_kernel<true>, dim3(blocks), dim3(kF16Threads), 0, st, a);
+    else hipLaunchKernelGGL(nerf_mlp_f16s_kernel<false>, dim3(blocks), dim3(kF16Threads), 0, st, a);
+    return check_launch("nerf_mlp_f16s_kernel");
   }
   if (precision == NERF_PREC_F16) {        // persistent workgroups, one per CU (147 KB of LDS each)
     const long long n_tiles = (a.n_points + kF16TilePts - 1) / kF16TilePts;
@@ -1062,7 +1130,7 @@ int32_t nerf_build_flags(void) {
 const char* nerf_last_error(void) { return g_err; }
 int64_t nerf_packed_model_bytes(int32_t precision) {
   if (precision == NERF_PREC_F32) return nerf::kPackedFloats * (int64_t)sizeof(float);
-  if (precision == NERF_PREC_F16) return nerf::kF16PackedBytes;
+  if (precision == NERF_PREC_F16 || precision == NERF_PREC_F16S) return nerf::kF16PackedBytes;
   if (precision == NERF_PREC_F32X) return nerf::kXPackedBytes;
   return -1;
 }
@@ -1076,10 +1144,11 @@ int32_t nerf_pack_model(const float* const params[24], void* packed, int32_t pre
   }
   a.out = (float*)packed;
   const int threads = 256;
-  if (precision == NERF_PREC_F16 || precision == NERF_PREC_F32X) {
+  if (precision == NERF_PREC_F16 || precision == NERF_PREC_F32X || precision == NERF_PREC_F16S) {
     const long long n = nerf::kF16ConstBytes / 4 + (long long)nerf::kF16Frags * 512;
     const dim3 grid((unsigned)((n + threads - 1) / threads));
-    if (precision == NERF_PREC_F16) hipLaunchKernelGGL(nerf_pack_f16_kernel<false>, grid, dim3(threads), 0, (hipStream_t)stream, a);
+    if (precision == NERF_PREC_F16S) hipLaunchKernelGGL(nerf_pack_f16s_kernel, grid, dim3(threads), 0, (hipStream_t)stream, a);
+    else if (precision == NERF_PREC_F16) hipLaunchKernelGGL(nerf_pack_f16_kernel<false>, grid, dim3(threads), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(nerf_pack_f16_kernel<true>, grid, dim3(threads), 0, (hipStream_t)stream, a);
     return check_launch("nerf_pack_f16_kernel");
   }

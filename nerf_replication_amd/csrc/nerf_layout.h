@@ -120,6 +120,51 @@ constexpr int kF16OffBias = 0;                   // 9 x [2][128]
 constexpr int kF16OffBiasViews = 9 * 256;        // [2][64]
 constexpr int kF16OffHeadBias = kF16OffBiasViews + 128;   // b_rgb[3], b_alpha
 
+// ---- fp16-activation path on v_mfma_f32_16x16x32_f16 ("f16s", nerf_mlp_f16s.hip.inc) -------------
+// Same arithmetic class and the same idea as the 32x32x16 path, on the other MFMA shape (the chip holds a higher clock on it,
+// MI355X_MICROARCH.md "DVFS give-back" item 7): D[16 out-features][16 points] += A[16][32 k] B[32 k][16 points], lane l = (c = l&15,
+// g = l>>4) holds rows 4g..4g+3 of its column c.  A wave still owns 32 points = two column groups (points 16n + c, n = 0, 1) that
+// share every A fragment.  The accumulators of out-tiles 2s and 2s+1 (16 features each), converted pairwise to fp16, are unchanged
+// the B fragment of k-step s of the next layer: element j of lane group g is feature
+//     act16s_feat(s, j, g) = 32 s + 16 (j >> 2) + 4 g + (j & 3).
+// A fragment of (out-tile m, k-step s): lane l = (i, g), element j = W[16 m + i][act16s_feat(s, j, g)]: 1 KiB as before, streamed
+// m-outer / k-inner through the same LDS ring.  Biases are read in NATURAL order (lane g, tile m: floats 16 m + 4 g ..+3).
+NERF_HD constexpr int act16s_feat(int s, int j, int g) { return 32 * s + 16 * (j >> 2) + 4 * g + (j & 3); }
+// xyz encoding: 64 slots per point = 16 per lane group = 8 (sin, cos) pairs: pairs 0..5 = octaves 2g, 2g+1 x (x, y, z); pairs
+// 6, 7 = "extras" x = 2g + e: x < 6: octave 8 + x/3 of coordinate x % 3; x = 6: the raw (x, y); x = 7: (z, pad).
+// Slot n of group g = element (n & 7) of PE k-step (n >> 3).
+NERF_HD constexpr int pe16s_xyz_feat(int n, int g) {
+  const int i = n >> 1, sc = n & 1;
+  if (i < 6) return 3 + 6 * (2 * g + i / 3) + 3 * sc + i % 3;
+  const int x = 2 * g + (i - 6);
+  if (x < 6) return 3 + 6 * (8 + x / 3) + 3 * sc + x % 3;
+  if (x == 6) return sc;                 // raw x, y
+  return sc == 0 ? 2 : -1;               // raw z, pad
+}
+// view direction: 32 slots = 8 per lane group: pairs 0..2 = octave g of (x, y, z); pair 3: g = 0 raw (x, y), g = 1 (z, pad), else pad
+NERF_HD constexpr int pe16s_dir_feat(int n, int g) {
+  const int i = n >> 1, sc = n & 1;
+  if (i < 3) return 3 + 6 * g + 3 * sc + i;
+  if (g == 0) return sc;
+  if (g == 1) return sc == 0 ? 2 : -1;
+  return -1;
+}
+// fragment ranges of the f16s stream (the sigma head again starts a chunk; 12 zero fragments pad the tail to whole chunks)
+constexpr int kF16sFragL0 = 0;                       // 16 m x 2 PE k-steps
+constexpr int kF16sFragL1 = 32;                      // L1..L4: 16 m x 8
+constexpr int kF16sFragL5 = kF16sFragL1 + 4 * 128;   // 16 m x (2 PE + 8 hidden) = 160
+constexpr int kF16sFragL6 = kF16sFragL5 + 160;       // L6, L7
+constexpr int kF16sFragSigma = kF16sFragL6 + 2 * 128; // 1 m (row 0) x 8
+constexpr int kF16sFragFeat = kF16sFragSigma + 8;    // 16 m x 8
+constexpr int kF16sFragViews = kF16sFragFeat + 128;  // 8 m x (8 feature + 1 dir)
+constexpr int kF16sFragRgb = kF16sFragViews + 72;    // 1 m (rows 0..2) x 4
+constexpr int kF16sFragEnd = kF16sFragRgb + 4;       // 1172
+static_assert(kF16sFragSigma == kF16FragSigma && kF16sFragEnd <= kF16Frags, "both fp16 streams: 37 chunks, sigma head at chunk 30");
+// const region (floats): biases in natural order
+constexpr int kF16sOffBias = 0;                      // 9 x [256]: pts_linears.0..7, feature_linear
+constexpr int kF16sOffBiasViews = 9 * 256;           // [128]
+constexpr int kF16sOffHeadBias = kF16sOffBiasViews + 128;   // b_rgb[3], b_alpha
+
 // ---- transposed stream for the backward (data-gradient) chain, nerf_mlp_bwd_f32.hip.inc -------
 // Same block format; A fragment of (k-step over the layer's OUTPUT features, out-tile over its INPUT
 // features) = W[act_feat(k-step, lane>>5)][input feature of row (lane&31)]; consumption order:

@@ -103,6 +103,7 @@ class RenderFunction(torch.autograd.Function):
             cap = getattr(renderer, "capture_adjoints", None)
             if cap is not None:       # tests: the per-ray sampler adjoint d loss / d raw_coarse and d loss / d t_sorted (parity attribution)
                 cap["g_raw_coarse"], cap["g_t_sorted"], cap["raw_coarse"] = g_raw_c.clone(), g_t.clone(), raw_c.clone()
+                cap["t_sorted"] = t_sorted.clone()
             _lib.check(lib.nerf_pack_model_bwd(_ptr_array([p.detach().contiguous() for p in params[:24]]), pk_b.data_ptr(), prec, st))
             gsave_c = gsave[: int(lib.nerf_train_grad_floats(n * S_c))]
             _lib.check(lib.nerf_mlp_backward_density(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(t_c), 0, n, S_c,

@@ -164,3 +164,94 @@ def pack_model_f16(sd, prefix, split=False):
     const[2432:2435] = g("rgb_linear.bias")
     const[2435] = g("alpha_linear.bias")[0]
     return const, stream
+
+
+# ------------------------------------------------------------------ f16s stream: 16x16x32 MFMA tiling (nerf_layout.h "f16s")
+def act16s_feat(s, j, g):
+    return 32 * s + 16 * (j >> 2) + 4 * g + (j & 3)
+
+
+def pe16s_xyz_feat(n, g):
+    i, sc = n >> 1, n & 1
+    if i < 6:
+        return 3 + 6 * (2 * g + i // 3) + 3 * sc + i % 3
+    x = 2 * g + (i - 6)
+    if x < 6:
+        return 3 + 6 * (8 + x // 3) + 3 * sc + x % 3
+    if x == 6:
+        return sc
+    return 2 if sc == 0 else -1
+
+
+def pe16s_dir_feat(n, g):
+    i, sc = n >> 1, n & 1
+    if i < 3:
+        return 3 + 6 * g + 3 * sc + i
+    if g == 0:
+        return sc
+    if g == 1:
+        return 2 if sc == 0 else -1
+    return -1
+
+
+def _frag_s(W, rows, colmap):
+    """One 1-KiB A fragment of the 16x16x32 tiling: lane l=(i,g), element j = W[rows[i]][colmap(j,g)], zero if row/col < 0."""
+    f = np.zeros((64, 8), np.float32)
+    for g in range(4):
+        for j in range(8):
+            c = colmap(j, g)
+            if c < 0:
+                continue
+            for i in range(16):
+                if rows[i] >= 0:
+                    f[16 * g + i, j] = W[rows[i], c]
+    return f.reshape(-1)
+
+
+def pack_model_f16s(sd, prefix):
+    """-> (const region float32 [4096]: biases in natural order, fragment stream float16 [1184*512]: 1172 fragments + 12 zero pads)."""
+    g = lambda n: sd[f"{prefix}.{n}"].detach().cpu().numpy().astype(np.float32)
+    frags = []
+    rows_of = lambda m: [16 * m + i for i in range(16)]
+    W0, W5 = g("pts_linears.0.weight"), g("pts_linears.5.weight")
+    for m in range(16):                                          # L0
+        for s in range(2):
+            frags.append(_frag_s(W0, rows_of(m), lambda j, gg, s=s: pe16s_xyz_feat(8 * s + j, gg)))
+    hidden = lambda W: [frags.append(_frag_s(W, rows_of(m), lambda j, gg, s=s: act16s_feat(s, j, gg)))
+                        for m in range(16) for s in range(8)]
+    for i in (1, 2, 3, 4):
+        hidden(g(f"pts_linears.{i}.weight"))
+    for m in range(16):                                          # L5: 2 PE + 8 hidden k-steps per m
+        for s in range(2):
+            frags.append(_frag_s(W5, rows_of(m), lambda j, gg, s=s: pe16s_xyz_feat(8 * s + j, gg)))
+        for s in range(8):
+            frags.append(_frag_s(W5, rows_of(m), lambda j, gg, s=s: 63 + act16s_feat(s, j, gg)))
+    for i in (6, 7):
+        hidden(g(f"pts_linears.{i}.weight"))
+    Wa = g("alpha_linear.weight")
+    for s in range(8):                                           # sigma head: row 0
+        frags.append(_frag_s(Wa, [0] + [-1] * 15, lambda j, gg, s=s: act16s_feat(s, j, gg)))
+    hidden(g("feature_linear.weight"))
+    Wv = g("views_linears.0.weight")
+    for m in range(8):                                           # views: 8 feature + 1 dir k-step
+        for s in range(8):
+            frags.append(_frag_s(Wv, rows_of(m), lambda j, gg, s=s: act16s_feat(s, j, gg)))
+
+        def col(j, gg):
+            c = pe16s_dir_feat(j, gg)
+            return -1 if c < 0 else 256 + c
+        frags.append(_frag_s(Wv, rows_of(m), col))
+    Wr = g("rgb_linear.weight")
+    for s in range(4):                                           # rgb head: rows 0..2
+        frags.append(_frag_s(Wr, [0, 1, 2] + [-1] * 13, lambda j, gg, s=s: act16s_feat(s, j, gg)))
+    assert len(frags) == 1172
+    frags += [np.zeros(512, np.float32)] * 12
+    stream = np.concatenate(frags).astype(np.float16)
+    const = np.zeros(4096, np.float32)
+    for i in range(8):
+        const[i * 256:(i + 1) * 256] = g(f"pts_linears.{i}.bias")
+    const[2048:2304] = g("feature_linear.bias")
+    const[2304:2432] = g("views_linears.0.bias")
+    const[2432:2435] = g("rgb_linear.bias")
+    const[2435] = g("alpha_linear.bias")[0]
+    return const, stream

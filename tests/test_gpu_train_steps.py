@@ -140,23 +140,34 @@ def test_training_trajectory_matches_reference(amd, oracle, golden, tag, precisi
     hip_vs_truth = vs_truth(lambda k: T.subsample(grads1[k]))
     ref_vs_truth = vs_truth(lambda k: g["grad1/" + k])
 
-    # ---- step 1, attributed: sampler + fine pass adjoint ON THE HIP PATH'S coarse densities -- the oracle in fp32 (torch autograd on
-    # the CPU) and in float64, against the HIP kernels' d loss / d sigma_coarse, ray by ray; rays on which the float64 sampler picks
-    # other bins than the fp32 one (a searchsorted / `denom < 1e-5` flip) are set aside and their share of the energy recorded
-    raw_c_hip = cap["raw_coarse"].cpu()
-    leaf_sd = {k: sd0[k].detach().clone().requires_grad_(True) for k in keys}
-    r32 = T.staged_step(oracle, leaf_sd, g["rays_o"], g["rays_d"], g["target"], raw_c_given=raw_c_hip)
-    r64 = T.staged_step_fp64(oracle, sd0, g["rays_o"], g["rays_d"], g["target"], raw_c_given=raw_c_hip)
-    b32, a32 = T.fp32_bins(oracle, raw_c_hip)
-    same_bins = ((b32 == r64["below"]) & (a32 == r64["above"])).all(1)
-    ga, g32, g64 = cap["g_raw_coarse"].cpu()[..., 3].double(), r32["g_raw_c"][..., 3].double(), r64["g_raw_c"][..., 3]
+    # ---- step 1, attributed stage by stage on the HIP path's OWN intermediates (captured in RenderFunction.backward), each stage
+    # against torch autograd of the CPU oracle in fp32 (the reference's arithmetic) and in float64 (the truth):
+    #  (i)  fine pass: d loss / d t_sorted at the HIP sampler's merged depths (compositing adjoint + MLP chain + d point / d t);
+    #  (ii) sampler: d / d sigma_coarse of that upstream gradient on the HIP path's coarse densities -- a LINEAR map of the
+    #       upstream gradient, so nothing but the adjoint arithmetic is compared; rays on which the float64 sampler picks other
+    #       bins than the fp32 one (a searchsorted / `denom < 1e-5` flip) are set aside and their share of the energy recorded.
+    # (Feeding only the densities and letting the oracle re-place the samples does not separate anything: any two implementations
+    #  place the fine samples of an ill-conditioned ray 1e-5 apart -- different exp() -- and the synthetic field changes by 1 % over
+    #  that distance: tests/test_noise_floor.py.)
+    raw_c_hip, ts_hip, gts_hip = cap["raw_coarse"].cpu(), cap["t_sorted"].cpu(), cap["g_t_sorted"].cpu()
+    gt32 = T.fine_pass_adjoint(oracle, sd0, g["rays_o"], g["rays_d"], g["target"], ts_hip)
+    gt64 = T.fine_pass_adjoint(oracle, sd0, g["rays_o"], g["rays_d"], g["target"], ts_hip, torch.float64)
+    sc_t = gt64.abs().amax(1).clamp_min(1e-30)
+    live_t = gt64.abs().amax(1) > 0
+    gt_hip_err = ((gts_hip.double() - gt64).abs().amax(1) / sc_t)[live_t]
+    gt_cpu_err = ((gt32.double() - gt64).abs().amax(1) / sc_t)[live_t]
+    q4 = lambda e: [torch.quantile(e, q).item() for q in (0.5, 0.9, 0.99, 1.0)] if e.numel() else [0.0] * 4
+    qt_hip, qt_cpu = q4(gt_hip_err), q4(gt_cpu_err)
+    g32, b32, a32 = T.sampler_adjoint(oracle, raw_c_hip, gts_hip)
+    g64, b64, a64 = T.sampler_adjoint(oracle, raw_c_hip, gts_hip, torch.float64)
+    same_bins = ((b32 == b64) & (a32 == a64)).all(1)
+    ga = cap["g_raw_coarse"].cpu()[..., 3].double()
     assert torch.all(cap["g_raw_coarse"][..., :3] == 0)
     n = ga.shape[0]
     scale = g64.abs().amax(1).clamp_min(1e-30)
-    err_hip, err_cpu = (ga - g64).abs().amax(1) / scale, (g32 - g64).abs().amax(1) / scale
+    err_hip, err_cpu = (ga - g64).abs().amax(1) / scale, (g32.double() - g64).abs().amax(1) / scale
     live_rays = same_bins & (g64.abs().amax(1) > 0)
-    qs = lambda e: [torch.quantile(e[live_rays], q).item() for q in (0.5, 0.9, 0.99, 1.0)] if live_rays.any() else [0.0] * 4
-    q_hip, q_cpu = qs(err_hip), qs(err_cpu)
+    q_hip, q_cpu = q4(err_hip[live_rays]), q4(err_cpu[live_rays])
     e2 = g64.norm(dim=1) ** 2
     share_excluded = (e2[~same_bins].sum() / e2.sum().clamp_min(1e-300)).item()
     # the coarse-density agreement itself (forward): HIP vs the reference's stored sigma of step 1
@@ -171,8 +182,9 @@ def test_training_trajectory_matches_reference(amd, oracle, golden, tag, precisi
               sigma_coarse_rel_err=sig_err,
               grad1_vs_fp64_truth={"hip_coarse": hip_vs_truth["model."], "reference_coarse": ref_vs_truth["model."],
                                    "hip_fine": hip_vs_truth["model_fine."], "reference_fine": ref_vs_truth["model_fine."]},
-              ray_adjoint_vs_fp64_truth={"rays": n, "same_bins_in_fp64": int(same_bins.sum()), "share_of_energy_in_excluded_rays": share_excluded,
-                                         "hip_q50_q90_q99_max": q_hip, "torch_cpu_fp32_q50_q90_q99_max": q_cpu},
+              fine_pass_adjoint_vs_fp64_truth={"hip_q50_q90_q99_max": qt_hip, "torch_cpu_fp32_q50_q90_q99_max": qt_cpu},
+              sampler_adjoint_vs_fp64_truth={"rays": n, "same_bins_in_fp64": int(same_bins.sum()), "share_of_energy_in_excluded_rays": share_excluded,
+                                             "hip_q50_q90_q99_max": q_hip, "torch_cpu_fp32_q50_q90_q99_max": q_cpu},
               paramK_fine_max_abs_diff=pK_f, paramK_coarse_max_abs_diff=pK_c, floor_paramK=floor["pdist"],
               coarse_live_fraction_step1=live[0], coarse_live_fraction_reference=g["coarse_live_fraction"].tolist(),
               coarse_live_fraction_after_K=live_after)
@@ -187,8 +199,9 @@ def test_training_trajectory_matches_reference(amd, oracle, golden, tag, precisi
     assert hip_vs_truth["model."] <= 2.0 * ref_vs_truth["model."] + 5e-3, (hip_vs_truth, ref_vs_truth)
     assert hip_vs_truth["model_fine."] <= 2.0 * ref_vs_truth["model_fine."] + 2e-4, (hip_vs_truth, ref_vs_truth)
     assert coarse <= 3.0 * ref_vs_truth["model."] + 5e-3                 # and the direct difference is inside that error class
-    # attributed, ray by ray on identical densities and identical bins: the HIP adjoint kernels against torch's fp32 autograd, both
-    # measured from the float64 truth
+    # attributed, ray by ray: (i) the fine pass's adjoint and (ii) the sampler's adjoint, HIP kernels and torch's fp32 autograd both
+    # measured from the float64 truth on identical inputs
+    assert qt_hip[2] <= 3.0 * qt_cpu[2] + 1e-4 and qt_hip[3] <= 3.0 * qt_cpu[3] + 1e-3, (qt_hip, qt_cpu)
     assert q_hip[2] <= 3.0 * q_cpu[2] + 1e-3 and q_hip[3] <= 3.0 * q_cpu[3] + 5e-3, (q_hip, q_cpu)
     assert q_hip[0] <= 3.0 * q_cpu[0] + 1e-4, (q_hip, q_cpu)
     assert flips_f <= 1e-3

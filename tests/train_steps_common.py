@@ -114,6 +114,50 @@ def staged_step_fp64(oracle, sd, o, d, target, raw_c_given=None):
     return dict(loss=loss.detach(), g_raw_c=g_raw_c, below=below, above=above, grads=grads)
 
 
+def fine_pass_adjoint(oracle, sd, o, d, target, t_sorted, dtype=torch.float32):
+    """Stage (i) of the attribution: d loss / d t_sorted of the fine pass alone -- points o + d t on GIVEN merged sample depths
+    -> fine network -> compositing -> MSE -- under torch autograd in `dtype` (fp32: the reference's arithmetic; float64: truth)."""
+    keys = [k for k in oracle.state_dict_keys() if k.startswith("model_fine.")]
+    sdx = {k: sd[k].detach().to(dtype) for k in keys}
+    o, d, target = o.to(dtype), d.to(dtype), target.to(dtype)
+    n = o.shape[0]
+    leaf = t_sorted.detach().to(dtype).clone().requires_grad_(True)
+    vd = d / torch.norm(d, dim=-1, keepdim=True)
+    pts = oracle.points_on_rays(o, d, leaf)
+    flat = pts.reshape(-1, 3)
+    dflat = vd[:, None].expand(n, leaf.shape[1], 3).reshape(-1, 3)
+    emb = torch.cat([oracle.freq_encode(flat, oracle.XYZ_FREQS), oracle.freq_encode(dflat, oracle.DIR_FREQS)], -1)
+    raw_f = oracle.nerf_mlp(sdx, "model_fine", emb).reshape(n, leaf.shape[1], 4)
+    rgb, _ = oracle.composite(raw_f, leaf, True)
+    torch.nn.functional.mse_loss(rgb, target).backward()
+    return leaf.grad.detach()
+
+
+def sampler_adjoint(oracle, raw_c, g_t_sorted, dtype=torch.float32):
+    """Stage (ii): d / d sigma_coarse of sum(t_sorted * G) through fine_sample + merge (volume_renderer.py:126-154, :247-264, :349-353)
+    under torch autograd in `dtype`, for given coarse outputs and a given upstream gradient.  Returns (g_sigma [n,64], below, above)."""
+    n = raw_c.shape[0]
+    leaf = raw_c.detach().to(dtype).clone().requires_grad_(True)
+    t_c = oracle.stratified_t().to(dtype).unsqueeze(0).expand(n, 64)
+    sigma = torch.relu(leaf[..., 3])
+    _, w = oracle.transmittance_weights(sigma, t_c)
+    w = w[:, 1:-1] + 1e-5
+    cdf = torch.cumsum(w / torch.sum(w, -1, keepdim=True), -1)
+    cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)
+    u = oracle.fine_u().to(dtype).expand(n, 128).contiguous()
+    inds = torch.searchsorted(cdf.detach(), u, right=True)
+    below, above = torch.clamp(inds - 1, 0, 61), torch.clamp(inds, 0, 61)
+    bins = 0.5 * (t_c[:, 1:] + t_c[:, :-1])
+    cb, ca = torch.gather(cdf, 1, below), torch.gather(cdf, 1, above)
+    bb, ba = torch.gather(bins, 1, below), torch.gather(bins, 1, above)
+    denom = ca - cb
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    t_f = bb + (u - cb) / denom * (ba - bb)
+    t_sorted, _ = torch.sort(torch.cat([t_c, t_f], 1), dim=-1)
+    (t_sorted * g_t_sorted.to(dtype)).sum().backward()
+    return leaf.grad.detach()[..., 3], below, above
+
+
 def fp32_bins(oracle, raw_c):
     """(below, above) of the fp32 sampler on these coarse outputs."""
     with torch.no_grad():
