@@ -30,7 +30,7 @@ KERNELS = ["_Z19nerf_mlp_f32_kernelILb1ELb0ELb0ELb0EEv7MlpArgs", "_Z19nerf_mlp_f
            "_Z23nerf_mlp_bwd_f32_kernelILb0EEv7BwdArgs", "_Z23nerf_mlp_bwd_f32_kernelILb1EEv7BwdArgs",
            "_Z28nerf_wgrad256_f32_asm_kernelILb0EEv10WgradBatch", "_Z28nerf_wgrad256_f32_asm_kernelILb1EEv10WgradBatch"]
 # every instance of these templates found in the ISA is checked too (their ring depth is part of the mangled name)
-KERNEL_PREFIXES = ["_Z29nerf_wgrad_vec_f32_asm_kernelI"]
+KERNEL_PREFIXES = ["_Z29nerf_wgrad_vec_f32_asm_kernelI", "_Z20nerf_mlp_f32x_kernelI"]
 
 
 def vregs(text):
@@ -53,43 +53,61 @@ def check(lines, name):
             label_at[t.split(":")[0]] = len(ins)                 # index of the first instruction after the label
         elif t and not t.startswith((";", ".")):
             ins.append((i, t))
-    in_asm = lambda idx: "ASMSTART" in K[ins[idx][0] - 1]
+    # source line -> inside an inline-asm block (";;#ASMSTART" ... ";;#ASMEND"; a block may hold several instructions)
+    asm_line, inside = set(), False
+    for i, l in enumerate(K):
+        if "ASMSTART" in l:
+            inside = True
+        elif "ASMEND" in l:
+            inside = False
+        elif inside:
+            asm_line.add(i)
+    in_asm = lambda idx: ins[idx][0] in asm_line
     is_vmem = lambda l: l.startswith(("global_", "buffer_", "scratch_", "flat_"))
-    asm_load = lambda idx: re.match(r"global_load_dword(x2|x4)?\b", ins[idx][1]) and "s[" in ins[idx][1] and in_asm(idx)
+    is_lds = lambda l: l.startswith("ds_")
+    asm_vm_load = lambda idx: re.match(r"global_load_dword(x2|x4)?\b", ins[idx][1]) and "s[" in ins[idx][1] and in_asm(idx)
+    # asm LDS reads (nerf_mlp_f32x.hip.inc and friends): covered by `s_waitcnt lgkmcnt(N)`.  LDS operations return in order, so a
+    # read has landed once at most N operations may be outstanding and >= N LDS operations were issued after it (scalar loads share
+    # the counter but complete out of order: they are NOT counted as younger operations -- that is the conservative direction)
+    asm_lds_load = lambda idx: re.match(r"ds_read_b(32|64|96|128)\b", ins[idx][1]) and in_asm(idx)
+    asm_load = lambda idx: asm_vm_load(idx) or asm_lds_load(idx)
     loads = [idx for idx in range(len(ins)) if asm_load(idx)]
     hazards = []
 
-    def walk(idx, dst, younger, depth, seen):
+    def walk(idx, dst, younger, depth, seen, lds):
         """Follow the control flow from instruction idx until a wait covers the load (at most `cnt` younger memory
         operations outstanding); report every instruction on the way that touches dst."""
         steps = 0
-        while idx < len(ins) and steps < 4000:
+        pat = r"lgkmcnt\((\d+)\)" if lds else r"vmcnt\((\d+)\)"
+        while idx < len(ins) and steps < 6000:
             steps += 1
             if (idx, younger) in seen:
                 return
             seen.add((idx, younger))
             l = ins[idx][1]
-            m = re.search(r"vmcnt\((\d+)\)", l) if l.startswith("s_waitcnt") else None
+            m = re.search(pat, l) if l.startswith("s_waitcnt") else None
             if m and younger >= int(m.group(1)):
                 return                                            # covered on this path
             touched = vregs(l.split(",")[0]) if asm_load(idx) else vregs(l)
             if touched & dst:
                 hazards.append(("touched before its wait", ld_text, l))
                 return
-            if is_vmem(l):
+            if (is_lds(l) if lds else is_vmem(l)):
                 younger += 1
             if l.startswith("s_endpgm"):
+                if lds:
+                    hazards.append(("never waited for before the end of the program", ld_text, l))
                 return
             if l.startswith("s_branch"):
                 idx = label_at[l.split()[1]]
                 continue
             if l.startswith("s_cbranch") and depth < 12:
-                walk(label_at[l.split()[1]], dst, younger, depth + 1, seen)
+                walk(label_at[l.split()[1]], dst, younger, depth + 1, seen, lds)
             idx += 1
 
     for ld in loads:
         ld_text = ins[ld][1]
-        walk(ld + 1, vregs(ld_text.split(",")[0]), 0, 0, set())
+        walk(ld + 1, vregs(ld_text.split(",")[0]), 0, 0, set(), bool(asm_lds_load(ld)))
     return len(loads), hazards
 
 
@@ -107,9 +125,10 @@ def main():
         lines = open(out).read().split("\n")
     bad = 0
     found = sorted({m.group(1) for l in lines for m in [re.match(r"^(_Z\w+):", l)] if m and m.group(1).startswith(tuple(KERNEL_PREFIXES))})
-    if not found:
-        print("    (no instance of", KERNEL_PREFIXES, "found)")
-        bad += 1
+    for pre in KERNEL_PREFIXES:
+        if not any(k.startswith(pre) for k in found):
+            print("    (no instance of", pre, "found)")
+            bad += 1
     for k in KERNELS + found:
         n, hz = check(lines, k)
         print(f"{k}: {n} asm loads, {len(hz)} hazards")
