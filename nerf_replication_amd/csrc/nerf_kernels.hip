@@ -484,6 +484,14 @@ void nerf_compact_kernel(const unsigned char* __restrict__ valid, long long n, i
   if (v) index[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (int)i;
 }
 
+// Point ids of the LAST sample of every ray (the fp16 paths' far-plane guard, nerf_render_forward): index[r] = r * S + S - 1.
+__global__ __launch_bounds__(256)
+void nerf_last_sample_index_kernel(int* __restrict__ index, int* __restrict__ count, long long n_rays, int S) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_rays) index[r] = (int)(r * S + S - 1);
+  if (r == 0) *count = (int)n_rays;
+}
+
 // ------------------------------------------------------------------------------------ compositing
 __global__ __launch_bounds__(256)
 void nerf_composite_kernel(const float* __restrict__ raw, const float* __restrict__ tvals,
@@ -1130,7 +1138,9 @@ int32_t nerf_build_flags(void) {
 const char* nerf_last_error(void) { return g_err; }
 int64_t nerf_packed_model_bytes(int32_t precision) {
   if (precision == NERF_PREC_F32) return nerf::kPackedFloats * (int64_t)sizeof(float);
-  if (precision == NERF_PREC_F16 || precision == NERF_PREC_F16S) return nerf::kF16PackedBytes;
+  // the fp16 streams carry the split-fp16 ("f32x") stream of the same model behind them: nerf_render_forward re-evaluates the
+  // last sample of every ray with it (far-plane guard)
+  if (precision == NERF_PREC_F16 || precision == NERF_PREC_F16S) return nerf::kF16PackedBytes + nerf::kXPackedBytes;
   if (precision == NERF_PREC_F32X) return nerf::kXPackedBytes;
   return -1;
 }
@@ -1150,6 +1160,11 @@ int32_t nerf_pack_model(const float* const params[24], void* packed, int32_t pre
     if (precision == NERF_PREC_F16S) hipLaunchKernelGGL(nerf_pack_f16s_kernel, grid, dim3(threads), 0, (hipStream_t)stream, a);
     else if (precision == NERF_PREC_F16) hipLaunchKernelGGL(nerf_pack_f16_kernel<false>, grid, dim3(threads), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(nerf_pack_f16_kernel<true>, grid, dim3(threads), 0, (hipStream_t)stream, a);
+    if (precision != NERF_PREC_F32X) {          // + the f32x stream behind the fp16 one
+      PackArgs ax = a;
+      ax.out = reinterpret_cast<float*>(reinterpret_cast<char*>(packed) + nerf::kF16PackedBytes);
+      hipLaunchKernelGGL(nerf_pack_f16_kernel<true>, grid, dim3(threads), 0, (hipStream_t)stream, ax);
+    }
     return check_launch("nerf_pack_f16_kernel");
   }
   if (precision != NERF_PREC_F32) return fail(NERF_ERR_UNSUPPORTED, "%s", "nerf_pack_model: unknown precision");
@@ -1715,10 +1730,11 @@ int32_t nerf_image_ssim(const float* pred, const float* gt, int32_t H, int32_t W
 int64_t nerf_render_workspace_bytes(int64_t n_rays, int32_t n_importance, int32_t fast_sampling) {
   if (n_rays < 0) return -1;
   const int64_t raw_c = align256(n_rays * NERF_N_SAMPLES * 4 * (int64_t)sizeof(float));
-  if (n_importance == 0) return raw_c;
+  if (n_importance == 0) return raw_c + align256(n_rays * (int64_t)sizeof(int)) + 256;
   const int64_t S = NERF_N_SAMPLES + NERF_N_IMPORTANCE;
   int64_t total = raw_c + align256(n_rays * S * (int64_t)sizeof(float)) + align256(n_rays * S * 4 * (int64_t)sizeof(float));
   if (fast_sampling) total += align256(n_rays * S) + align256(n_rays * S * (int64_t)sizeof(int)) + 256;   // mask, index, count
+  else total += align256(n_rays * (int64_t)sizeof(int)) + 256;                                            // last-sample ids, count (fp16 far-plane guard)
   return total;
 }
 
@@ -1749,8 +1765,31 @@ int32_t nerf_render_forward(const float* rays_o, const float* rays_d, int64_t n_
   int rc = n_importance ? nerf_mlp_forward_rays_density(rays_o, rays_d, t_coarse, 0, n_rays, NERF_N_SAMPLES, packed_coarse, raw_c, precision, stream)
                         : nerf_mlp_forward_rays(rays_o, rays_d, t_coarse, 0, n_rays, NERF_N_SAMPLES, packed_coarse, raw_c, precision, stream);
   if (rc) return rc;
-  if (n_importance == 0)
+  // fp16 far-plane guard.  The last sample of a ray has delta = 1e10 (volume_renderer.py:85-86): ANY sigma > 0 there makes alpha = 1, so
+  // an fp16 rounding that flips the sign of a sigma within 1e-2 of zero turns a background ray into a full far-plane hit (round 2:
+  // single rays off by 0.64 in rgb and 6.0 in depth, which alone set the fp16 PSNR).  Every other sample's alpha moves by
+  // |d sigma| * delta ~ 1e-4.  So the fp16 precisions re-evaluate exactly that sample of every ray (0.5 % of the points) with the
+  // split-fp16 stream that rides behind their packed model: fp32-accurate sigma and colour where it matters, ~1.5 % of the frame.
+  const bool guard = (precision == NERF_PREC_F16 || precision == NERF_PREC_F16S) && n_rays <= (int64_t)0x7fffffff / (NERF_N_SAMPLES + NERF_N_IMPORTANCE);
+  auto far_plane_guard = [&](const float* tvals, int64_t stride, int32_t S_, const void* packed_f16, float* raw, char* ids_base) -> int {
+    int* index = (int*)ids_base;
+    int* count = (int*)(ids_base + align256(n_rays * (int64_t)sizeof(int)));
+    hipLaunchKernelGGL(nerf_last_sample_index_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, index, count,
+                       (long long)n_rays, S_);
+    int r2 = check_launch("nerf_last_sample_index_kernel");
+    if (r2) return r2;
+    MlpArgs g{};
+    g.rays_o = rays_o; g.rays_d = rays_d; g.tvals = tvals; g.t_ray_stride = stride; g.n_points = n_rays * S_;
+    g.n_samples = S_; g.packed = (const float*)((const char*)packed_f16 + nerf::kF16PackedBytes); g.raw = raw; g.index = index; g.count = count;
+    return launch_mlp(g, true, NERF_PREC_F32X, (hipStream_t)stream);
+  };
+  if (n_importance == 0) {
+    if (guard) {
+      rc = far_plane_guard(t_coarse, 0, NERF_N_SAMPLES, packed_coarse, raw_c, ws + align256(n_rays * NERF_N_SAMPLES * 4 * (int64_t)sizeof(float)));
+      if (rc) return rc;
+    }
     return nerf_composite(raw_c, t_coarse, 0, n_rays, NERF_N_SAMPLES, white_bkgd, rgb, depth, nullptr, stream);
+  }
   const int64_t S = NERF_N_SAMPLES + NERF_N_IMPORTANCE;
   float* t_sorted = (float*)(ws + align256(n_rays * NERF_N_SAMPLES * 4 * (int64_t)sizeof(float)));
   float* raw_f = (float*)((char*)t_sorted + align256(n_rays * S * (int64_t)sizeof(float)));
@@ -1760,6 +1799,10 @@ int32_t nerf_render_forward(const float* rays_o, const float* rays_d, int64_t n_
     // the fine outputs only ever reach nerf_composite: colours of zero-density samples are multiplied by exactly 0 there
     rc = nerf_mlp_forward_rays_for_compositing(rays_o, rays_d, t_sorted, S, n_rays, (int32_t)S, packed_fine, raw_f, precision, stream);
     if (rc) return rc;
+    if (guard) {
+      rc = far_plane_guard(t_sorted, S, (int32_t)S, packed_fine, raw_f, (char*)raw_f + align256(n_rays * S * 4 * (int64_t)sizeof(float)));
+      if (rc) return rc;
+    }
   } else {
     // ESS/ERT (volume_renderer.py:359-369, network.py:207-253): only the valid merged samples go through
     // the fine network; the others keep raw = 0 (sigma 0 -> weight 0)

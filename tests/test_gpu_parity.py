@@ -485,9 +485,13 @@ def net16(amd, synthetic_sd, request):
 def test_f16_pack_matches_layout_reference(net16, synthetic_sd, model, prefix):
     got = net16.packed(model).cpu()
     const, stream = (pack_reference.pack_model_f16s if net16.precision == "f16s" else pack_reference.pack_model_f16)(synthetic_sd, prefix)
-    assert got.numel() == 16384 + 1184 * 1024
+    n16 = 16384 + 1184 * 1024
+    assert got.numel() == n16 + 16384 + 2368 * 1024           # + the split-fp16 stream of the far-plane guard behind it
     assert np.array_equal(got[:16384].view(torch.float32).numpy(), const)
-    assert np.array_equal(got[16384:].view(torch.float16).numpy(), stream)
+    assert np.array_equal(got[16384:n16].view(torch.float16).numpy(), stream)
+    xconst, xstream = pack_reference.pack_model_f16(synthetic_sd, prefix, split=True)
+    assert np.array_equal(got[n16:n16 + 16384].view(torch.float32).numpy(), xconst)
+    assert np.array_equal(got[n16 + 16384:].view(torch.float16).numpy(), xstream)
 
 
 def test_f16_network_forward(net16, golden):
