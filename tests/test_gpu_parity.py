@@ -434,7 +434,8 @@ def test_render_rejects_cpu_and_bad_args(amd, net):
     assert b"null" in lib.nerf_last_error()
     assert lib.nerf_render_forward(None, None, 4, None, None, None, None, 64, 1, 0, 0, 0.25, None, 0, None, None, None) == -1
     assert lib.nerf_render_forward(None, None, 0, None, None, None, None, 128, 1, 0, 0, 0.25, None, 0, None, None, None) == 0
-    assert lib.nerf_render_workspace_bytes(1000, 128, 0) == 1000 * (1024 + 768 + 3072)
+    # raw_coarse + t_sorted + raw_fine, + the last-sample ids and count of the fp16 far-plane guard (4 B per ray, 256-aligned, + 256)
+    assert lib.nerf_render_workspace_bytes(1000, 128, 0) == 1000 * (1024 + 768 + 3072) + 4096 + 256
     # masked fine pass: (ray, sample) ids are int32 -> more than 2^31 / 192 rays per call is refused, not wrapped
     # (the check precedes every launch; the dummy non-null pointers are never dereferenced)
     big = (2 ** 31) // 192 + 1

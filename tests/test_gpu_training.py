@@ -56,9 +56,9 @@ def test_forward_save_matches_reference_activations(amd, net, golden, precision)
         hv = sv[P * (96 + 2304):rows].view(P, 128)
         assert _rel(f, g[f"{tag}_feature"]) <= 2e-5 and _rel(hv, g[f"{tag}_views"]) <= 2e-5
         assert _rel(raw[:, 0], g[f"{tag}_out"]) <= 2e-5
-        if precision == "f32":
-            # behind the rows (fp32 SAVE forward only): ReLU sign bits in accumulator layout, one 1-KiB block per
-            # 32-point tile and masked tensor (h0..h7, views), and the xyz encoding in B-operand layout
+        if precision in ("f32", "f32x"):
+            # behind the rows (both SAVE forwards, same layout): ReLU sign bits in accumulator layout, one 1-KiB block per
+            # 32-point tile and masked tensor (h0..h7, views)
             bits = sv[rows:rows + (P // 32) * 9 * 256].view(torch.int32).view(P // 32, 9, 64, 4)
             lane = torch.arange(64)
             pt, hh = lane & 31, lane >> 5
