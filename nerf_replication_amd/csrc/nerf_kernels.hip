@@ -725,11 +725,11 @@ void nerf_sample_bwd_kernel(const float* __restrict__ raw_c, const float* __rest
   __shared__ float s_tc[S];
   __shared__ float s_u[F];
   __shared__ float s_cdf[4][S];
-  __shared__ float s_gcdf[4][S];
+  __shared__ double s_gcdf[4][S];          // adjoint of the cdf, accumulated in float64 (see below)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (threadIdx.x < S) s_tc[threadIdx.x] = t_coarse[threadIdx.x];
   if (threadIdx.x < F) s_u[threadIdx.x] = u_tab[threadIdx.x];
-  s_gcdf[wv][lane] = 0.0f;
+  s_gcdf[wv][lane] = 0.0;
   __syncthreads();
   const long long ray_slot = (long long)blockIdx.x * 4 + wv;
   const bool ray_ok = ray_slot < n_rays;                       // a wave past the end recomputes the last ray and stores nothing
@@ -773,7 +773,11 @@ void nerf_sample_bwd_kernel(const float* __restrict__ raw_c, const float* __rest
   // ---- the two fine samples of this lane: bin, merged slot, adjoint into g_cdf
   const float* gts = g_tsorted + ray * (S + F);
   float* cdf = s_cdf[wv];
-  float* gcdf = s_gcdf[wv];
+  // Everything downstream of the (fp32, forward-identical) decisions is accumulated in float64: the terms num / denom^2 of an
+  // ill-conditioned ray (denom ~ 1e-5) are 1e5 x the result of the sums they enter, and the fp32 version of these sums (LDS float
+  // atomics + wave scans) was 10-20 x further from a float64 evaluation of the adjoint than torch's fp32 autograd on the same
+  // inputs (tests/test_gpu_train_steps.py, round 3).  The kernel is 20 us of a training step either way.
+  double* gcdf = s_gcdf[wv];
   int ic_carry = 0;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -800,41 +804,41 @@ void nerf_sample_bwd_kernel(const float* __restrict__ raw_c, const float* __rest
     }
     ic = max(ic, ic_carry);
     ic_carry = __shfl(ic, 63);
-    const float g = gts[k + ic];                                // its slot in the merged array
-    const float g_frac = g * __fsub_rn(ba, bb);
-    float g_cb = -g_frac / denom, g_ca = 0.0f;                  // frac = (u - cb) / denom, denom = ca - cb when live
-    if (live) { const float gden = -g_frac * num / (denom * denom); g_ca += gden; g_cb -= gden; }
+    const double g = (double)gts[k + ic];                       // its slot in the merged array
+    const double g_frac = g * (double)__fsub_rn(ba, bb);
+    double g_cb = -g_frac / (double)denom, g_ca = 0.0;          // frac = (u - cb) / denom, denom = ca - cb when live
+    if (live) { const double gden = -g_frac * (double)num / ((double)denom * (double)denom); g_ca += gden; g_cb -= gden; }
     atomicAdd(&gcdf[below], g_cb);
     atomicAdd(&gcdf[above], g_ca);
   }
   __syncthreads();
   // ---- cdf[m] = sum_{j<m} pdf_j  ->  g_pdf_j = sum_{m>j} g_cdf[m];  pdf = we / W
-  float sfx = lane < NB ? gcdf[lane] : 0.0f;                    // inclusive suffix sum over the lanes
+  double sfx = lane < NB ? gcdf[lane] : 0.0;                    // inclusive suffix sum over the lanes
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
-    const float o = __shfl_down(sfx, d);
+    const double o = __shfl_down(sfx, d);
     if (lane + d < 64) sfx += o;
   }
-  float gpdf_excl = __shfl_down(sfx, 1);                        // lane j: g_pdf_j = sum_{m>j} g_cdf[m]
-  if (lane == 63) gpdf_excl = 0.0f;
-  float gpdf_i = __shfl_up(gpdf_excl, 1);                       // lane i: g_pdf of bin i - 1 (the bin of sample i)
-  if (!inner) gpdf_i = 0.0f;
-  float dot = inner ? gpdf_i * we : 0.0f;
+  double gpdf_excl = __shfl_down(sfx, 1);                       // lane j: g_pdf_j = sum_{m>j} g_cdf[m]
+  if (lane == 63) gpdf_excl = 0.0;
+  double gpdf_i = __shfl_up(gpdf_excl, 1);                      // lane i: g_pdf of bin i - 1 (the bin of sample i)
+  if (!inner) gpdf_i = 0.0;
+  double dot = inner ? gpdf_i * (double)we : 0.0;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) dot += __shfl_xor(dot, d);
-  const float g_w = inner ? (gpdf_i / wsum - dot / (wsum * wsum)) : 0.0f;
-  float sf2 = g_w * alpha * Ti;                                 // suf_i = sum_{m>i} g_w_m a_m T_m
+  const double g_w = inner ? (gpdf_i / (double)wsum - dot / ((double)wsum * (double)wsum)) : 0.0;
+  double sf2 = g_w * (double)alpha * (double)Ti;                // suf_i = sum_{m>i} g_w_m a_m T_m
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
-    const float o = __shfl_down(sf2, d);
+    const double o = __shfl_down(sf2, d);
     if (lane + d < 64) sf2 += o;
   }
-  float suf = __shfl_down(sf2, 1);
-  if (lane == 63) suf = 0.0f;
-  float g_alpha = g_w * Ti;
-  if (om >= 1e-10f && om <= 1.0f) g_alpha -= suf / q;
+  double suf = __shfl_down(sf2, 1);
+  if (lane == 63) suf = 0.0;
+  double g_alpha = g_w * (double)Ti;
+  if (om >= 1e-10f && om <= 1.0f) g_alpha -= suf / (double)q;
   f32x4 go = {0.f, 0.f, 0.f, 0.f};
-  go.w = s_raw > 0.0f ? g_alpha * delta * e : 0.0f;
+  go.w = s_raw > 0.0f ? (float)(g_alpha * (double)delta * (double)e) : 0.0f;
   if (ray_ok) reinterpret_cast<f32x4*>(g_raw_c)[ray * S + i] = go;
 }
 
