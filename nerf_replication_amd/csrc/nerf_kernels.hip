@@ -367,6 +367,33 @@ __device__ __forceinline__ float alpha_of(float sigma, float delta) {
   return __fsub_rn(1.0f, expf(__fmul_rn(-sigma, delta)));       // 1 - exp(-sigma*delta)
 }
 
+// torch.sum(w, -1) of volume_renderer.py:138 on a 62-element fp32 row, in the CPU kernel's own order (ATen SumKernel.cpp,
+// vectorized_inner_sum / row_sum with 8-lane vectors and 4 accumulators -- verified bit for bit against torch.sum on the fixture
+// rows): the 56 leading elements as 7 vectors of 8, lane sums ((((((v0 + v4) + v5) + v6) + v1) + v2) + v3), then the 6 tail
+// elements and the 8 lane sums added one by one.  A plain left-to-right sum (rounds 1-2) is off by up to 3e-6 relative on rows of
+// many equal 1e-5 terms, i.e. cdf[62] = 1 + 3e-6: it moved every fine sample of a ray by ~3e-6 against the reference's and was
+// the "unexplained" part of the white-noise family's excess over the noise floor (round-2 VERDICT Weak 8).
+template <class Get>
+__device__ __forceinline__ float torch_sum62_of(Get x) {
+  float P[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float p = __fadd_rn(x(j), x(32 + j));
+    p = __fadd_rn(p, x(40 + j));
+    p = __fadd_rn(p, x(48 + j));
+    p = __fadd_rn(p, x(8 + j));
+    p = __fadd_rn(p, x(16 + j));
+    P[j] = __fadd_rn(p, x(24 + j));
+  }
+  float acc = x(56);
+#pragma unroll
+  for (int k = 57; k < 62; ++k) acc = __fadd_rn(acc, x(k));
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __fadd_rn(acc, P[j]);
+  return acc;
+}
+__device__ __forceinline__ float torch_sum62(const float* w) { return torch_sum62_of([&](int k) { return w[k]; }); }
+
 __global__ __launch_bounds__(kSampleThreads)
 void nerf_sample_fine_kernel(SampleArgs a) {
   constexpr int S = NERF_N_SAMPLES, F = NERF_N_IMPORTANCE, NB = S - 1;   // 63 cdf entries / bins
@@ -400,14 +427,14 @@ void nerf_sample_fine_kernel(SampleArgs a) {
     const float w = __fmul_rn(T, alpha);
     if (i >= 1 && i <= S - 2) {
       const float we = __fadd_rn(w, 1e-5f);
-      cdf[i - 1] = we;                                  // stash w+eps in cdf slots 0..61
-      wsum = __fadd_rn(wsum, we);
+      cdf[i - 1] = we;                                  // stash w+eps in cdf slots 0..61 (summed below, in torch's order)
       if (w < a.weights_threshold) empty_bits |= 1ull << (i - 1);
       ert_seen = ert_seen || (T < a.ert_threshold);     // cummax of (T < thr) over the inner bins
       if (ert_seen) ert_bits |= 1ull << (i - 1);
     }
     T = __fmul_rn(T, fminf(fmaxf(__fsub_rn(1.0f, alpha), 1e-10f), 1.0f));
   }
+  wsum = torch_sum62(cdf);
   const bool empty_ray = dsum < 1e-3f;
   const bool object_ray = dmax > 0.5f;
   // cdf = [0, cumsum(pdf)]  (63 entries)
@@ -755,9 +782,7 @@ void nerf_sample_bwd_kernel(const float* __restrict__ raw_c, const float* __rest
   }
   const bool inner = i >= 1 && i <= S - 2;
   const float we = __fadd_rn(__fmul_rn(Ti, alpha), 1e-5f);     // w + eps (used for the inner 62 only)
-  float wsum = 0.0f;
-#pragma unroll
-  for (int j = 1; j <= S - 2; ++j) wsum = __fadd_rn(wsum, lane_bcast(we, j));
+  const float wsum = torch_sum62_of([&](int k) { return lane_bcast(we, k + 1); });     // bin k <-> lane k + 1; the forward's order
   const float pdf = __fdiv_rn(we, wsum);                       // lane i: pdf of bin i - 1
   float cdf_m = 0.0f;                                          // lane m: cdf[m], m = 0..62
   {
