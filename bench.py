@@ -331,12 +331,12 @@ def run_config5(pkg, sd, dev, world, rank, steps=2):
     rays_per_s = n * steps / elapsed
     # executed FLOP per ray: the coarse launch is density-only (see the headline's config.coarse_pass) and waves without
     # density skip the colour branch in the fine launch: counted from the sigma output of one more pass over this shard
-    st5 = time_stages(pkg, net, ren, o, d, 1, prec=1, full_coarse=True)
+    st5 = time_stages(pkg, net, ren, o, d, 1, prec=pkg._lib.PRECISIONS["f16"], full_coarse=True)
     dead5, tiles5 = st5["_dead_fine_tiles"], st5["_fine_tiles"]
     flop_per_ray = 64 * (FLOP_PER_POINT - FLOP_DENSITY_SKIPPED) + 192 * FLOP_PER_POINT - dead5 * 32 * FLOP_DENSITY_SKIPPED / max(1, hi - lo)
     ms5 = elapsed / steps * 1e3
     full5 = n / ((ms5 + st5["mlp_coarse_full_network"] - st5["mlp_coarse"] + st5["mlp_fine_full_network"] - st5["mlp_fine"]) * 1e-3)
-    return {"workload": "1600x1600 frame = 2560000 rays, 64+128 (coarse pass density-only), fp16 activations + fp32 accumulate (nerf_mlp_f16_kernel)",
+    return {"workload": "1600x1600 frame = 2560000 rays, 64+128 (coarse pass density-only), fp16 activations + fp32 accumulate (nerf_mlp_f16s_kernel: 16x16x32 MFMA tiles; the last sample of every ray re-evaluated with the split-fp16 stream: far-plane guard)",
             "rays_per_s": round(rays_per_s, 1), "ms_per_frame": round(elapsed / steps * 1e3, 2), "steps": steps, "warmup": 1,
             "n_gpus": world, "finite": finite,
             "roofline": {"bound": "mfma", "achieved": round(rays_per_s * flop_per_ray / 1e12, 1),
@@ -396,7 +396,7 @@ def main():
                          "ms_per_step_without_dead_tile_skip (profiles/collect.sh: keeps the rocprofv3 rows of the timed steps clean)")
     ap.add_argument("--no-extras", dest="extras", action="store_false",
                     help="skip the training (configs[2]) and 1600x1600 f16 (configs[4]) blocks that follow the headline")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32x", "f16s"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16", "f32x", "f16m32"],
                     help="f32 (default, the reference's dtype: exact fp32 MFMA), f16 (BASELINE config 5: fp16 "
                          "activations, fp32 accumulate) or f32x (fp32-accurate: hi/lo split operands, 3 fp16 MFMAs per product)")
     args = ap.parse_args()
@@ -522,7 +522,7 @@ def main():
         pass
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
                 "frac": round(achieved / (peak / 1e12), 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": f"nerf_mlp_{args.precision}_kernel", "avg_launch_ms": round(mlp_ms_per_launch, 3),
+                "kernel": {"f32": "nerf_mlp_f32_kernel", "f16": "nerf_mlp_f16s_kernel", "f16m32": "nerf_mlp_f16_kernel", "f32x": "nerf_mlp_f32x_kernel"}[args.precision], "avg_launch_ms": round(mlp_ms_per_launch, 3),
                 "flop_per_frame_executed": flop_frame_executed, "flop_per_frame_reference_algorithm": flop_frame_reference,
                 "fine_tiles_without_density": {"tiles": dead_tiles, "of": fine_tiles,
                                                "note": "32-sample tiles whose sigma is <= 0 throughout: weight exactly 0 in compositing; "
@@ -552,8 +552,8 @@ def main():
         out = {"metric": f"rays/sec ({H}x{W}, 64+128 samples)" + (", ESS/ERT masked fine pass" if args.fast_sampling else ""), "value": round(value, 1), "unit": "rays/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-               "dtype": {0: "f32", 1: "f16 (fp32 accumulate)", 2: "f32 emulated (hi/lo fp16 split x3, fp32 accumulate)",
-                         3: "f16 (fp32 accumulate, 16x16x32 MFMA tiles)"}[prec],
+               "dtype": {0: "f32", 1: "f16 (fp32 accumulate, 32x32x16 MFMA tiles)", 2: "f32 emulated (hi/lo fp16 split x3, fp32 accumulate)",
+                         3: "f16 (fp32 accumulate)"}[prec],
                "data": "synthetic",
                "config": {"workload": f"lego-shaped {H}x{W} frame = {H * W} pinhole rays, 64 coarse + 128 fine "
                                       "hierarchical samples, 8+1-layer W=256 NeRF x2, seeded synthetic weights "

@@ -16,7 +16,10 @@ PREC_F32 = 0
 PREC_F16 = 1
 PREC_F32X = 2
 PREC_F16S = 3          # fp16 arithmetic on 16x16x32 MFMA tiles (A/B partner of PREC_F16's 32x32x16 tiles)
-PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "f16": PREC_F16, "fp16": PREC_F16, "f32x": PREC_F32X, "f16s": PREC_F16S}
+# "f16" is the fp16-activation path of BASELINE config 5.  Both MFMA shapes are built and tested; the 16x16x32 kernel measured
+# 0.3-0.9 % (fine launch) / 3 % (coarse launch) faster in interleaved A/Bs (profiles/r03_f16_variants.csv) and is what "f16"
+# selects; "f16m32" selects the 32x32x16 kernel explicitly.
+PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "f16": PREC_F16S, "fp16": PREC_F16S, "f16s": PREC_F16S, "f16m32": PREC_F16, "f32x": PREC_F32X}
 
 _c = ctypes
 _F = _c.c_void_p   # device pointers travel as integers (tensor.data_ptr())

@@ -113,8 +113,7 @@ if "train" in tag:
 # traffic_<prec>.json: what bench.py reports as roofline.traffic (per launch of the dominant kernel, averaged over the
 # coarse and fine launches exactly as `rocprofv3 --stats` averages their durations)
 prec = tag.split("_", 1)[1] if (tag[:1] == "r" and "train" not in tag) else None
-kname = {"f32": "nerf_mlp_f32_kernel", "f16": "nerf_mlp_f16_kernel", "f32x": "nerf_mlp_f32x_kernel", "f16s": "nerf_mlp_f16s_kernel",
-         "f32xs": "nerf_mlp_f32xs_kernel"}.get(prec)
+kname = {"f32": "nerf_mlp_f32_kernel", "f16": "nerf_mlp_f16s_kernel", "f32x": "nerf_mlp_f32x_kernel", "f16m32": "nerf_mlp_f16_kernel"}.get(prec)
 if kname:
     import json
     per, clk_num, clk_den = {}, 0.0, 0.0

@@ -34,7 +34,9 @@ HARD_MAX = {"base": (8e-4, 3e-3), "sharp": (1e-4, 1e-3), "white": (6e-2, 2.5e-1)
 # the reference against its own fp64-MLP self: 19 of 3072, tests/test_noise_floor.py)
 # "trained" (a network trained by the build, tests/golden/trained_ckpt.pth): SURVEY 8c's flat per-ray tolerance holds on EVERY ray
 # (measured max 8.2e-5 / 4.5e-4 over 4096 + 1024 rays) -- its smooth coarse pdf has no empty bins, so no sample flips
-MAX_OVER_FRAC = {"base": 0.01, "sharp": 0.01, "white": 0.03, "trained": 0.0}
+# round 3: with the sampler summing its 62 weights in torch.sum's own order (nerf_kernels.hip torch_sum62) the white-noise family went
+# from 53 to 33 rays of 4096 outside the tolerance (the reference against its fp64-MLP self: 19 of 3072 = 25 per 4096) -> 2 %
+MAX_OVER_FRAC = {"base": 0.01, "sharp": 0.01, "white": 0.02, "trained": 0.0}
 
 
 def image_stats(oracle, rgb, dep, ref_rgb, ref_dep):
@@ -179,7 +181,7 @@ def test_mlp_rays_mode_points_bit_exact(amd, net, golden):
     assert _chan_err(raw_rays, g["raw_fine"]) <= RAW_RTOL
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16", "f32x", "f16s"])
+@pytest.mark.parametrize("precision", ["f32", "f16", "f32x", "f16m32"])
 @pytest.mark.parametrize("n_rays,S,stride", [(256, 192, 192), (1000, 64, 0), (3, 64, 0)])     # per-ray depths; the shared coarse table; a ragged tile
 def test_density_only_forward_is_the_full_forwards_sigma(amd, synthetic_sd, golden, precision, n_rays, S, stride):
     """nerf_mlp_forward_rays_density (the coarse pass of nerf_render_forward when N_importance > 0: the reference reads only
@@ -207,7 +209,7 @@ def test_density_only_forward_is_the_full_forwards_sigma(amd, synthetic_sd, gold
     assert torch.all(dens[..., :3] == 0)
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16", "f32x", "f16s"])
+@pytest.mark.parametrize("precision", ["f32", "f16", "f32x", "f16m32"])
 @pytest.mark.parametrize("family", ["base", "sharp", "white", "trained"])
 def test_compositing_forward_drops_only_colours_that_are_multiplied_by_zero(amd, golden, family_sd, family, precision):
     """nerf_mlp_forward_rays_for_compositing (the fine pass of nerf_render_forward) vs nerf_mlp_forward_rays on the reference's
@@ -408,7 +410,10 @@ def test_family_parity_attributed(amd, oracle, golden, family_sd, family, rays):
     # attribution, every ray, hard -- measured <= 7e-6 / 5.2e-5 on all six scenes, i.e. far inside SURVEY 8c's figures
     assert a_st["rgb_max"] <= 2e-5 and a_st["depth_max"] <= 2e-4, st
     assert st["rays_over_tolerance"] <= MAX_OVER_FRAC[family] * n, st
-    assert st["psnr_db"] >= {"base": 95.0, "sharp": 110.0, "white": 58.0, "trained": 110.0}[family], st    # measured 107.8 / 115.1 / 65.5 / 118.5
+    # the bulk (restored in round 3; round 2 had dropped it after the white-noise family measured 1.23e-4 -- that excess was the
+    # sampler's left-to-right weight sum, now 5.2e-5 .. 7.0e-5 on that family)
+    assert st["rgb_q99"] <= EPS_RGB and st["depth_q99"] <= EPS_DEP, st
+    assert st["psnr_db"] >= {"base": 95.0, "sharp": 110.0, "white": 60.0, "trained": 110.0}[family], st    # measured 107.8 / 115.2 / 67.2 / 123.7
     assert st["rgb_max"] <= HARD_MAX[family][0] and st["depth_max"] <= HARD_MAX[family][1], st
     # the sampler itself (same inputs): moves beyond a bin's rounding amplification are flips; a handful per 65 536
     assert st["sampler_same_inputs"]["samples_moved_gt_1e-3"] <= 0.001 * n * 128, st     # measured <= 22 of 65 536
@@ -471,9 +476,9 @@ def test_full_frame_properties(amd, net, oracle, synthetic_sd):
 # =============================================================================== fp16 activation path
 # BASELINE config 5: fp16 activations/weights, fp32 accumulate.  Not the parity path: the bar is
 # PSNR vs the reference render (north_star: >= 30 dB); measured ~45-60 dB, asserted >= 40 dB.
-# Both MFMA shapes of the fp16 arithmetic run every test of this section: "f16" (v_mfma_f32_32x32x16_f16) and "f16s"
-# (v_mfma_f32_16x16x32_f16, round-2 VERDICT item 3).
-@pytest.fixture(scope="module", params=["f16", "f16s"])
+# Both MFMA shapes of the fp16 arithmetic run every test of this section: "f16" (the shipped one: v_mfma_f32_16x16x32_f16, round-2
+# VERDICT item 3) and "f16m32" (v_mfma_f32_32x32x16_f16).
+@pytest.fixture(scope="module", params=["f16m32", "f16"])
 def net16(amd, synthetic_sd, request):
     n = amd.Network()
     n.load_state_dict(synthetic_sd, strict=True)
@@ -485,7 +490,7 @@ def net16(amd, synthetic_sd, request):
 @pytest.mark.parametrize("model,prefix", [("", "model"), ("fine", "model_fine")])
 def test_f16_pack_matches_layout_reference(net16, synthetic_sd, model, prefix):
     got = net16.packed(model).cpu()
-    const, stream = (pack_reference.pack_model_f16s if net16.precision == "f16s" else pack_reference.pack_model_f16)(synthetic_sd, prefix)
+    const, stream = (pack_reference.pack_model_f16 if net16.precision == "f16m32" else pack_reference.pack_model_f16s)(synthetic_sd, prefix)
     n16 = 16384 + 1184 * 1024
     assert got.numel() == n16 + 16384 + 2368 * 1024           # + the split-fp16 stream of the far-plane guard behind it
     assert np.array_equal(got[:16384].view(torch.float32).numpy(), const)
@@ -864,10 +869,13 @@ def test_family_parity_large_sample(amd, oracle, family_sd, family):
     print(family, st)
     # attribution, every one of the 4096 rays: measured <= 1.7e-5 / 9.9e-5 (sharp), i.e. 6x / 10x inside SURVEY 8c's figures
     assert a_st["rgb_max"] <= 5e-5 and a_st["depth_max"] <= 5e-4, st
-    assert st["rays_over_tolerance"] <= MAX_OVER_FRAC[family] * n, st                  # measured 4 / 2 / 53 of 4096
-    assert st["psnr_db"] >= {"base": 95.0, "sharp": 95.0, "white": 58.0, "trained": 105.0}[family], st    # measured 102.4 / 110.1 / 71.8 / 115.8
+    assert st["rays_over_tolerance"] <= MAX_OVER_FRAC[family] * n, st                  # measured 4 / 2 / 33 / 0 of 4096 (round 2: 53 on white)
+    assert st["rgb_q99"] <= EPS_RGB and st["depth_q99"] <= EPS_DEP, st
+    assert st["psnr_db"] >= {"base": 95.0, "sharp": 95.0, "white": 70.0, "trained": 105.0}[family], st    # measured 102.4 / 110.5 / 80.2 / 117.4
     if family != "white":
         assert st["rays_over_tolerance_without_moved_sample"] == 0, st
+    else:                       # (white: 4 of 4096, round 2: 9)
+        assert st["rays_over_tolerance_without_moved_sample"] <= 0.002 * n, st
 
 
 def test_render_is_hipgraph_capturable(amd, net, oracle):
@@ -919,7 +927,7 @@ def test_f16_and_f32x_psnr_on_every_family(amd, oracle, golden, family_sd, famil
     g = golden(f"render_family_{family}.npz")
     sd = family_sd(family)
     out = {}
-    for prec in ("f16", "f32x", "f16s"):
+    for prec in ("f16", "f32x", "f16m32"):
         net = amd.Network()
         net.load_state_dict(sd, strict=True)
         net = net.cuda().eval()
@@ -933,7 +941,13 @@ def test_f16_and_f32x_psnr_on_every_family(amd, oracle, golden, family_sd, famil
         out[f"{prec}/worst_psnr_db"] = worst
     parity_record("other_precisions_vs_reference", family, out)
     print(family, {k: (v if not isinstance(v, dict) else (v["psnr_db"], v["rays_over_tolerance"])) for k, v in out.items()})
-    assert out["f16/worst_psnr_db"] >= 30.0 and out["f16s/worst_psnr_db"] >= 30.0, out
+    # BASELINE's bar is 30 dB; with the far-plane guard (nerf_render_forward re-evaluates the last sample of every ray with the
+    # split-fp16 stream) measured 54 / 56 / 48 / 82 dB (round 2, without it: 34.5 / 34.0 / 47.9 / 78.2)
+    floor16 = {"base": 45.0, "sharp": 45.0, "white": 40.0, "trained": 70.0}[family]
+    assert out["f16/worst_psnr_db"] >= floor16 and out["f16m32/worst_psnr_db"] >= floor16, out
+    for prec in ("f16", "f16m32"):
+        for rays in ("seed", "pin"):
+            assert out[f"{prec}/{rays}"]["depth_max"] <= 1.0, out       # no background ray becomes a far-plane hit (round 2: 6.0)
     assert out["f32x/worst_psnr_db"] >= {"base": 95.0, "sharp": 95.0, "white": 55.0, "trained": 105.0}[family], out
     for rays in ("seed", "pin"):
         assert out[f"f32x/{rays}"]["rays_over_tolerance"] <= max(1, MAX_OVER_FRAC[family] * 512), out

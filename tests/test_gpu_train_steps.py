@@ -193,7 +193,9 @@ def test_training_trajectory_matches_reference(amd, oracle, golden, tag, precisi
 
     assert loss_rel[0] <= 1e-5                                           # the forward
     assert (cap["raw_coarse"][..., 3].cpu() > 0).float().mean().item() == pytest.approx(g["coarse_live_fraction"][0].item(), abs=2e-4)
-    assert fine <= 2e-3                                                  # smooth in the rounding (reference vs its fp64-MLP self: 1.5e-4 .. 6e-4)
+    # the fine gradient against the reference's: inside the class of the reference's own distance from the float64 truth (trained
+    # batch: 4.4e-3 -- a converged fine network is sharp, sample positions that differ by 1e-6 move it by 3e-3; synthetic: 4.5e-4)
+    assert fine <= 3.0 * ref_vs_truth["model_fine."] + 2e-4, (fine, ref_vs_truth)
     # the HIP gradients are as close to the float64 truth as the reference's own fp32 gradients are (measured, trained batch:
     # reference 5.7e-2 coarse / 4.4e-3 fine)
     assert hip_vs_truth["model."] <= 2.0 * ref_vs_truth["model."] + 5e-3, (hip_vs_truth, ref_vs_truth)

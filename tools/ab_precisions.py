@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of arithmetic paths / MFMA shapes INSIDE one library, interleaved rounds in one process (cdna_hip_programming.md rule 24).
 
-    python tools/ab_precisions.py f16 f16s            # fine launch (160 000 rays x 192 samples) of each, AB_ROUNDS rounds
+    python tools/ab_precisions.py f16m32 f16            # fine launch (160 000 rays x 192 samples) of each, AB_ROUNDS rounds
     python tools/ab_precisions.py f32x f32xs
 
 Reports per precision the median / min launch time (HIP events on the launch stream) and the algorithmic TFLOP/s; the data
@@ -19,7 +19,7 @@ import nerf_replication_amd as pkg  # noqa: E402
 
 
 def main():
-    names = sys.argv[1:] or ["f16", "f16s"]
+    names = sys.argv[1:] or ["f16m32", "f16"]
     rounds = int(os.environ.get("AB_ROUNDS", "7"))
     kind = os.environ.get("AB_KIND", "fine")
     n = int(os.environ.get("AB_RAYS", "160000"))
