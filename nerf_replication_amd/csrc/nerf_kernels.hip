@@ -22,10 +22,10 @@
 // nerf_build_flags(), which the Python loader (and any other binder) checks -- so a stray -D can no longer produce a
 // library that passes nerf_abi_version() and computes garbage.
 #define NERF_ANY_TIMING_HACK (NERF_F32_HACK_NOLOAD || NERF_F32_HACK_NOBIAS || NERF_F32_HACK_NORELU || NERF_F32_HACK_NOPE || \
-                              NERF_F32_HACK_NOHEADS || NERF_F32_ASM_OVERRUN || NERF_F32_HACK_NOSAVE || NERF_BWD_HACK_NOMASK || NERF_BWD_HACK_NOGZ || NERF_F16_HACK_NOADV || NERF_F16_HACK_NOBARRIER || NERF_WG_HACK_NOATOMIC || NERF_F16_HACK_NOEPI || NERF_F16_HACK_NOBIAS || NERF_F16_HACK_NORELU || NERF_F32X_HACK_NOADV || \
+                              0 || NERF_F32_ASM_OVERRUN || NERF_F32_HACK_NOSAVE || NERF_BWD_HACK_NOMASK || 0 || NERF_F16_HACK_NOADV || NERF_F16_HACK_NOBARRIER || NERF_WG_HACK_NOATOMIC || NERF_F16_HACK_NOEPI || 0 || NERF_F16_HACK_NORELU || NERF_F32X_HACK_NOADV || \
                               NERF_F32X_HACK_NOPE || NERF_F32X_HACK_NOEPI)
 // (two structural knobs of the SAVE forward also break results when switched off: no rows / no sign bits stored)
-#if (NERF_ANY_TIMING_HACK || NERF_SAVE_TAPS == 0 || NERF_SAVE_BITS == 0) && !defined(NERF_TIMING_BUILD)
+#if (NERF_ANY_TIMING_HACK || NERF_SAVE_TAPS == 0 || 2 == 0) && !defined(NERF_TIMING_BUILD)
 #error "a NERF_*_HACK_* / NERF_F32_ASM_OVERRUN timing switch is set: such a library computes wrong results; build it with -DNERF_TIMING_BUILD (tools/ab_bench.py does) so that nerf_build_flags() reports it"
 #endif
 
@@ -1076,7 +1076,7 @@ bool dead_tile_list_available(long long P, int precision) {
   const char* env = getenv("NERF_DEAD_TILE_SKIP");
   const bool want = !(env && env[0] == '0');
   return want && (precision == NERF_PREC_F32 || precision == NERF_PREC_F32X) && NERF_WGRAD_ASM && NERF_WGVEC_ASM &&
-         NERF_F32_DEAD_SKIP && P % 32 == 0 && P / 32 <= 0x7fffffffLL;
+         P % 32 == 0 && P / 32 <= 0x7fffffffLL;
 }
 __global__ void nerf_check_stamp_kernel(const float* __restrict__ stamp, float* __restrict__ poison) {
   if (threadIdx.x == 0 && __float_as_int(stamp[0]) != 0) poison[0] = __int_as_float(0x7fc00000);
@@ -1103,7 +1103,7 @@ int launch_mlp(const MlpArgs& a, bool ray_mode, int precision, hipStream_t st) {
     const long long n_tiles = (a.n_points + kXTilePts - 1) / kXTilePts;
     const unsigned blocks = (unsigned)(n_tiles < num_cus() ? n_tiles : num_cus());
     if (ray_mode && a.density_only) hipLaunchKernelGGL((nerf_mlp_f32x_kernel<true, false, true>), dim3(blocks), dim3(kXThreads), 0, st, a);
-    else if (ray_mode && a.skip_dead_colour && NERF_F32_DEAD_SKIP) hipLaunchKernelGGL((nerf_mlp_f32x_kernel<true, false, false, true>), dim3(blocks), dim3(kXThreads), 0, st, a);
+    else if (ray_mode && a.skip_dead_colour) hipLaunchKernelGGL((nerf_mlp_f32x_kernel<true, false, false, true>), dim3(blocks), dim3(kXThreads), 0, st, a);
     else if (ray_mode) hipLaunchKernelGGL(nerf_mlp_f32x_kernel<true>, dim3(blocks), dim3(kXThreads), 0, st, a);
     else hipLaunchKernelGGL(nerf_mlp_f32x_kernel<false>, dim3(blocks), dim3(kXThreads), 0, st, a);
     return check_launch("nerf_mlp_f32x_kernel");
@@ -1112,7 +1112,7 @@ int launch_mlp(const MlpArgs& a, bool ray_mode, int precision, hipStream_t st) {
     const long long n_tiles = (a.n_points + kF16TilePts - 1) / kF16TilePts;
     const unsigned blocks = (unsigned)(n_tiles < num_cus() ? n_tiles : num_cus());
     if (ray_mode && a.density_only) hipLaunchKernelGGL((nerf_mlp_f16s_kernel<true, true>), dim3(blocks), dim3(kF16Threads), 0, st, a);
-    else if (ray_mode && a.skip_dead_colour && NERF_F32_DEAD_SKIP) hipLaunchKernelGGL((nerf_mlp_f16s_kernel<true, false, true>), dim3(blocks), dim3(kF16Threads), 0, st, a);
+    else if (ray_mode && a.skip_dead_colour) hipLaunchKernelGGL((nerf_mlp_f16s_kernel<true, false, true>), dim3(blocks), dim3(kF16Threads), 0, st, a);
     else if (ray_mode) hipLaunchKernelGGL(nerf_mlp_f16s_kernel<true>, dim3(blocks), dim3(kF16Threads), 0, st, a);
     else hipLaunchKernelGGL(nerf_mlp_f16s_kernel<false>, dim3(blocks), dim3(kF16Threads), 0, st, a);
     return check_launch("nerf_mlp_f16s_kernel");
@@ -1121,7 +1121,7 @@ int launch_mlp(const MlpArgs& a, bool ray_mode, int precision, hipStream_t st) {
     const long long n_tiles = (a.n_points + kF16TilePts - 1) / kF16TilePts;
     const unsigned blocks = (unsigned)(n_tiles < num_cus() ? n_tiles : num_cus());
     if (ray_mode && a.density_only) hipLaunchKernelGGL((nerf_mlp_f16_kernel<true, true>), dim3(blocks), dim3(kF16Threads), 0, st, a);
-    else if (ray_mode && a.skip_dead_colour && NERF_F32_DEAD_SKIP) hipLaunchKernelGGL((nerf_mlp_f16_kernel<true, false, true>), dim3(blocks), dim3(kF16Threads), 0, st, a);
+    else if (ray_mode && a.skip_dead_colour) hipLaunchKernelGGL((nerf_mlp_f16_kernel<true, false, true>), dim3(blocks), dim3(kF16Threads), 0, st, a);
     else if (ray_mode) hipLaunchKernelGGL(nerf_mlp_f16_kernel<true>, dim3(blocks), dim3(kF16Threads), 0, st, a);
     else hipLaunchKernelGGL(nerf_mlp_f16_kernel<false>, dim3(blocks), dim3(kF16Threads), 0, st, a);
     return check_launch("nerf_mlp_f16_kernel");
@@ -1132,13 +1132,10 @@ int launch_mlp(const MlpArgs& a, bool ray_mode, int precision, hipStream_t st) {
 #endif
   const long long tiles = (a.n_points + nerf::kTilePts - 1) / nerf::kTilePts;
   long long blocks = (tiles + NERF_F32_WG_WAVES - 1) / NERF_F32_WG_WAVES;
-#if NERF_F32_PERSISTENT
-  if (blocks > num_cus()) blocks = num_cus();          // 512 registers per wave: exactly one workgroup per CU
-#endif
   if (blocks > 0x7fffffffLL) return fail(NERF_ERR_INVALID_ARG, "%s", "too many points for one launch");
   // density_only (ray mode): every precision has an instance that stops after the sigma head
   if (ray_mode && a.density_only) hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, false, true>), dim3((unsigned)blocks), dim3(64 * NERF_F32_WG_WAVES), 0, st, a);
-  else if (ray_mode && a.skip_dead_colour && NERF_F32_DEAD_SKIP)
+  else if (ray_mode && a.skip_dead_colour)
     hipLaunchKernelGGL((nerf_mlp_f32_kernel<true, false, false, true>), dim3((unsigned)blocks), dim3(64 * NERF_F32_WG_WAVES), 0, st, a);
   else if (ray_mode) hipLaunchKernelGGL(nerf_mlp_f32_kernel<true>, dim3((unsigned)blocks), dim3(64 * NERF_F32_WG_WAVES), 0, st, a);
   else hipLaunchKernelGGL(nerf_mlp_f32_kernel<false>, dim3((unsigned)blocks), dim3(64 * NERF_F32_WG_WAVES), 0, st, a);
@@ -1159,7 +1156,7 @@ int32_t nerf_build_flags(void) {
 #ifdef NERF_TIMING_BUILD
   f |= NERF_BUILD_TIMING;
 #endif
-#if NERF_ANY_TIMING_HACK || NERF_SAVE_TAPS == 0 || NERF_SAVE_BITS == 0
+#if NERF_ANY_TIMING_HACK || NERF_SAVE_TAPS == 0 || 2 == 0
   f |= NERF_BUILD_WRONG_NUMERICS;
 #endif
   return f;
@@ -1337,9 +1334,9 @@ static int32_t wgrad_impl(const float* dz, int64_t ldz, int32_t zc0, int32_t n_o
   long long blocks = (pairs + 255) / 256;            // >= 256 point pairs per workgroup
   if (blocks > num_cus()) blocks = num_cus();
   if (blocks < 1) blocks = 1;
-  // the small-layer (vector-load) kernels may run NERF_WGVEC_WAVES workgroups per CU
+  // the small-layer (vector-load) kernels: one workgroup per CU (more resident waves measured no faster)
   long long vblocks = (pairs + 255) / 256;
-  if (vblocks > (long long)num_cus() * NERF_WGVEC_WAVES) vblocks = (long long)num_cus() * NERF_WGVEC_WAVES;
+  if (vblocks > (long long)num_cus()) vblocks = (long long)num_cus();
   if (vblocks < 1) vblocks = 1;
   const dim3 grid((unsigned)blocks), vgrid((unsigned)vblocks), blk(256);
   hipStream_t st = (hipStream_t)stream;
@@ -1382,11 +1379,11 @@ static int32_t wgrad_impl(const float* dz, int64_t ldz, int32_t zc0, int32_t n_o
     } else hipLaunchKernelGGL((nerf_wgrad_vec_f32_kernel<AV, BV>), vgrid, blk, 0, st, a); \
   } while (0)
   else if (n_out == 256 && n_in <= 64 && aligned) VEC(4, 1, NERF_WGVEC_PF41, 2, 2);         // PE -> 256 (layers 0 and 5)
-  else if (n_out == 128 && n_in == 256 && aligned) VEC(4, 2, NERF_WGVEC_PF42, 1, 4);        // views_linears.0, feature part
-  else if (n_out == 128 && n_in <= 32) VEC(1, 1, NERF_WGVEC_PF11, 4, 1);                    // views_linears.0, direction part
+  else if (n_out == 128 && n_in == 256 && aligned) VEC(4, 2, 16, 1, 4);        // views_linears.0, feature part
+  else if (n_out == 128 && n_in <= 32) VEC(1, 1, 16, 4, 1);                    // views_linears.0, direction part
   else if (n_out <= 32 && n_in == 256 && ldh % 2 == 0 && hc0 % 2 == 0 && (uintptr_t)hin % 8 == 0)
-    VEC(1, 2, NERF_WGVEC_PF12, 1, 4);                                                       // alpha_linear
-  else if (n_out <= 32 && n_in <= 128) VEC(1, 1, NERF_WGVEC_PF11, 1, 4);                    // rgb_linear
+    VEC(1, 2, 16, 1, 4);                                                       // alpha_linear
+  else if (n_out <= 32 && n_in <= 128) VEC(1, 1, 16, 1, 4);                    // rgb_linear
 #undef VEC
   else if (to > 4 && ti > 4) { a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<4, 4>), grid, blk, 0, st, a); }
   else if (to > 4)           { a.osplit = 2; a.isplit = 2; hipLaunchKernelGGL((nerf_wgrad_f32_kernel<4, 1>), grid, blk, 0, st, a); }
