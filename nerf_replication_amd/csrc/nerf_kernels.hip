@@ -1753,8 +1753,22 @@ int32_t nerf_image_ssim(const float* pred, const float* gt, int32_t H, int32_t W
   return check_launch("nerf_ssim_kernel");
 }
 
-int64_t nerf_render_workspace_bytes(int64_t n_rays, int32_t n_importance, int32_t fast_sampling) {
-  if (n_rays < 0) return -1;
+// Ray blocks.  nerf_render_forward walks a frame in blocks of kRenderBlockRays rays (the four stages per block, same stream): the
+// intermediates -- raw_coarse, t_sorted, raw_fine: 4864 B per ray -- then belong to ONE block, so the workspace is 320 MB whatever the
+// frame (round 2: 3.1 GB at 800x800, 12.5 GB at 1600x1600) and what one stage writes is still in the 256-MB Infinity Cache when the
+// next stage reads it.  Rays are independent, so the image is bit-identical to the one-block render; 65 536 rays are 6 144 (fp32:
+// 393 216) workgroup tiles per fine launch, i.e. the launch tail stays below 1 %.  NERF_RENDER_BLOCK_RAYS in the environment
+// overrides the block size (A/B).
+static constexpr int64_t kRenderBlockRays = 65536;
+static int64_t render_block_rays() {
+  const char* env = getenv("NERF_RENDER_BLOCK_RAYS");
+  if (env) { const long long v = atoll(env); if (v >= 64) return (int64_t)v; }
+  return kRenderBlockRays;
+}
+
+int64_t nerf_render_workspace_bytes(int64_t n_rays_frame, int32_t n_importance, int32_t fast_sampling) {
+  if (n_rays_frame < 0) return -1;
+  const int64_t n_rays = n_rays_frame < render_block_rays() ? n_rays_frame : render_block_rays();
   const int64_t raw_c = align256(n_rays * NERF_N_SAMPLES * 4 * (int64_t)sizeof(float));
   if (n_importance == 0) return raw_c + align256(n_rays * (int64_t)sizeof(int)) + 256;
   const int64_t S = NERF_N_SAMPLES + NERF_N_IMPORTANCE;
@@ -1763,6 +1777,10 @@ int64_t nerf_render_workspace_bytes(int64_t n_rays, int32_t n_importance, int32_
   else total += align256(n_rays * (int64_t)sizeof(int)) + 256;                                            // last-sample ids, count (fp16 far-plane guard)
   return total;
 }
+
+static int32_t render_block(const float* rays_o, const float* rays_d, int64_t n_rays, const void* packed_coarse, const void* packed_fine,
+                            const float* t_coarse, const float* u, int32_t n_importance, int32_t white_bkgd, int32_t precision,
+                            int32_t fast_sampling, float weights_threshold, void* workspace, float* rgb, float* depth, void* stream);
 
 int32_t nerf_render_forward(const float* rays_o, const float* rays_d, int64_t n_rays,
                             const void* packed_coarse, const void* packed_fine,
@@ -1783,6 +1801,20 @@ int32_t nerf_render_forward(const float* rays_o, const float* rays_d, int64_t n_
   if (fast_sampling && n_importance && n_rays > (int64_t)0x7fffffff / (NERF_N_SAMPLES + NERF_N_IMPORTANCE))
     return fail(NERF_ERR_INVALID_ARG, "%s", "nerf_render_forward: fast_sampling handles at most 11 184 810 rays per call "
                                             "(n_rays * 192 point ids must fit in int32): split the frame");
+  const int64_t B = render_block_rays();
+  for (int64_t r0 = 0; r0 < n_rays; r0 += B) {
+    const int64_t nb = n_rays - r0 < B ? n_rays - r0 : B;
+    const int rc = render_block(rays_o + 3 * r0, rays_d + 3 * r0, nb, packed_coarse, packed_fine, t_coarse, u, n_importance, white_bkgd,
+                                precision, fast_sampling, weights_threshold, workspace, rgb + 3 * r0, depth + r0, stream);
+    if (rc) return rc;
+  }
+  return NERF_OK;
+}
+
+// one block of rays through the four stages (workspace: nerf_render_workspace_bytes of the block)
+static int32_t render_block(const float* rays_o, const float* rays_d, int64_t n_rays, const void* packed_coarse, const void* packed_fine,
+                            const float* t_coarse, const float* u, int32_t n_importance, int32_t white_bkgd, int32_t precision,
+                            int32_t fast_sampling, float weights_threshold, void* workspace, float* rgb, float* depth, void* stream) {
   char* ws = (char*)workspace;
   float* raw_c = (float*)ws;
   // hierarchical render: the coarse network only places the fine samples -- nothing but its sigma is read
