@@ -1754,12 +1754,14 @@ int32_t nerf_image_ssim(const float* pred, const float* gt, int32_t H, int32_t W
 }
 
 // Ray blocks.  nerf_render_forward walks a frame in blocks of kRenderBlockRays rays (the four stages per block, same stream): the
-// intermediates -- raw_coarse, t_sorted, raw_fine: 4864 B per ray -- then belong to ONE block, so the workspace is 320 MB whatever the
-// frame (round 2: 3.1 GB at 800x800, 12.5 GB at 1600x1600) and what one stage writes is still in the 256-MB Infinity Cache when the
-// next stage reads it.  Rays are independent, so the image is bit-identical to the one-block render; 65 536 rays are 6 144 (fp32:
-// 393 216) workgroup tiles per fine launch, i.e. the launch tail stays below 1 %.  NERF_RENDER_BLOCK_RAYS in the environment
-// overrides the block size (A/B).
-static constexpr int64_t kRenderBlockRays = 65536;
+// intermediates -- raw_coarse, t_sorted, raw_fine: 4864 B per ray -- belong to ONE block, so the workspace is bounded (5.1 GB) whatever
+// the frame (round 2: 12.5 GB at 1600x1600, growing with the frame).  Rays are independent: the image is bit-identical to the one-block
+// render (tests).  The block is LARGE on purpose: with 65 536-ray blocks (320 MB, Infinity-Cache-resident intermediates) the fp32
+// frame lost 0.2 % and the fp16 frame 5 % (134.7 -> 141.4 ms at 800x800) -- every block pays the persistent kernels' pipeline fill and
+// tail, and the far-plane guard's launch (one point per ray) fills 2 tiles per CU -- while nothing is gained from the cache
+// residency: the MLP launches are matrix-bound and HBM sits at < 1 % of its bandwidth either way.  NERF_RENDER_BLOCK_RAYS in the
+// environment overrides the block size (A/B, tests).
+static constexpr int64_t kRenderBlockRays = 1 << 20;
 static int64_t render_block_rays() {
   const char* env = getenv("NERF_RENDER_BLOCK_RAYS");
   if (env) { const long long v = atoll(env); if (v >= 64) return (int64_t)v; }

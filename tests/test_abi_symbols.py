@@ -32,8 +32,10 @@ def test_library_builds_loads_and_exports():
     lib.nerf_packed_model_bytes.argtypes = [ctypes.c_int32]
     # f32: 2 x K=64 layers + 8 x K=256 layers + views (K=288 -> 128) + biases + heads
     assert lib.nerf_packed_model_bytes(0) == 4 * (2 * 64 * 256 + 8 * 256 * 256 + 288 * 128 + 9 * 256 + 128 + 256 + 384 + 4)
-    # f16: 16 KiB const region + 1184 A fragments of 1 KiB (37 chunks of 32)
-    assert lib.nerf_packed_model_bytes(1) == 16384 + 1184 * 1024
+    # f16 (both MFMA shapes): 16 KiB const region + 1184 A fragments of 1 KiB (37 chunks of 32), + the split-fp16 stream of the same
+    # model behind it (16 KiB + 2368 fragments: the far-plane guard of nerf_render_forward); f32x: that stream alone
+    assert lib.nerf_packed_model_bytes(1) == lib.nerf_packed_model_bytes(3) == (16384 + 1184 * 1024) + (16384 + 2368 * 1024)
+    assert lib.nerf_packed_model_bytes(2) == 16384 + 2368 * 1024
     assert lib.nerf_packed_model_bytes(7) == -1
     lib.nerf_render_workspace_bytes.restype = ctypes.c_int64
     lib.nerf_render_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]

@@ -450,6 +450,35 @@ def test_render_rejects_cpu_and_bad_args(amd, net):
     assert lib.nerf_build_flags() == 0            # product build: no timing switch compiled in
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16", "f32x"])
+def test_ray_blocks_change_nothing(amd, synthetic_sd, oracle, monkeypatch, precision):
+    """nerf_render_forward walks the frame in ray blocks (bounded workspace).  With 1024-ray blocks (five blocks, the last one
+    ragged) the image is bit-identical to the one-block render: 64+128, coarse only, and the masked (ESS/ERT) fine pass; the fp16
+    far-plane guard runs per block."""
+    n = 4500
+    ids = torch.randperm(800 * 800, generator=torch.Generator().manual_seed(12))[:n]
+    o, d = oracle.pinhole_rays(800, 800, oracle.camera_pose(63.0), pixel_ids=ids)
+    net = amd.Network(); net.load_state_dict(synthetic_sd); net = net.cuda().eval(); net.precision = precision
+    out = {}
+    for tag, env in (("one", "100000000"), ("blocks", "1024")):
+        monkeypatch.setenv("NERF_RENDER_BLOCK_RAYS", env)
+        ren = amd.Renderer(net)
+        res = []
+        for n_imp, fast in ((128, False), (0, False), (128, True)):
+            ren.N_importance, ren.fast_sampling, ren.weights_threshold = n_imp, fast, 0.02
+            with torch.no_grad():
+                rgb, dep = ren.render({"rays_o": o[None].cuda(), "rays_d": d[None].cuda()})
+            res.append((rgb.clone(), dep.clone()))
+        out[tag] = res
+    monkeypatch.delenv("NERF_RENDER_BLOCK_RAYS")
+    for (ra, da), (rb, db) in zip(out["one"], out["blocks"]):
+        assert torch.isfinite(rb).all() and torch.equal(ra, rb) and torch.equal(da, db)
+    lib = amd._lib.load()
+    monkeypatch.setenv("NERF_RENDER_BLOCK_RAYS", "1024")
+    assert lib.nerf_render_workspace_bytes(10 ** 7, 128, 0) == lib.nerf_render_workspace_bytes(1024, 128, 0)      # bounded by the block
+    monkeypatch.delenv("NERF_RENDER_BLOCK_RAYS")
+
+
 def test_full_frame_properties(amd, net, oracle, synthetic_sd):
     """BASELINE config 2 size (800x800 = 640 000 rays, 64+128): size-independent properties, plus the
     oracle on a random 512-ray subset."""
