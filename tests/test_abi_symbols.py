@@ -39,8 +39,11 @@ def test_library_builds_loads_and_exports():
     assert lib.nerf_packed_model_bytes(7) == -1
     lib.nerf_render_workspace_bytes.restype = ctypes.c_int64
     lib.nerf_render_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
-    assert lib.nerf_render_workspace_bytes(640000, 128, 0) == 640000 * 4864
-    assert lib.nerf_render_workspace_bytes(640000, 0, 0) == 640000 * 1024
+    # 4864 B per ray (raw_coarse, t_sorted, raw_fine) + the fp16 far-plane guard's last-sample ids and count; bounded by one ray
+    # block of 2^20 rays whatever the frame
+    assert lib.nerf_render_workspace_bytes(640000, 128, 0) == 640000 * 4864 + 640000 * 4 + 256
+    assert lib.nerf_render_workspace_bytes(10 ** 8, 128, 0) == lib.nerf_render_workspace_bytes(1 << 20, 128, 0)
+    assert lib.nerf_render_workspace_bytes(640000, 0, 0) == 640000 * 1024 + 640000 * 4 + 256
     assert lib.nerf_render_workspace_bytes(640000, 128, 1) == 640000 * (4864 + 192 + 768) + 256
 
 
