@@ -1492,8 +1492,8 @@ int32_t nerf_pack_model_bwd(const float* const params[24], void* packed_bwd_v, i
 // grads[24]: device pointers in state_dict order (nn.Linear layouts), accumulated into (caller zeroes them)
 // shared by the ray-mode and the point-mode entry: data-gradient chain, then the weight / bias gradients
 static int32_t mlp_backward_impl(const BwdArgs& a_in, bool pts_mode, float* const grads[24], int32_t precision, void* stream) {
-  // density only: the fp32 chain skips the colour branch in the kernel; the split-fp16 chain computes it (on zeros), but its
-  // three weight-gradient jobs are skipped on the host all the same: their result is exactly zero either way
+  // density only: both chains skip the colour branch in the kernel (ray mode), and its three weight-gradient jobs are skipped
+  // here: their result is exactly zero
   BwdArgs a = a_in;
   const bool dens = a.density_only != 0;
   const long long P = a.n_points;
@@ -1539,6 +1539,7 @@ static int32_t mlp_backward_impl(const BwdArgs& a_in, bool pts_mode, float* cons
     const long long n_tiles = (P + kXTilePts - 1) / kXTilePts;
     const unsigned blocks = (unsigned)(n_tiles < num_cus() ? n_tiles : num_cus());
     if (pts_mode) hipLaunchKernelGGL(nerf_mlp_bwd_f32x_kernel<true>, dim3(blocks), dim3(kXThreads), 0, (hipStream_t)stream, a);
+    else if (dens) hipLaunchKernelGGL((nerf_mlp_bwd_f32x_kernel<false, true>), dim3(blocks), dim3(kXThreads), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(nerf_mlp_bwd_f32x_kernel<false>, dim3(blocks), dim3(kXThreads), 0, (hipStream_t)stream, a);
     rc = check_launch("nerf_mlp_bwd_f32x_kernel");
   } else if (precision == NERF_PREC_F32) {
@@ -1680,14 +1681,16 @@ static int32_t forward_rays_save_impl(const float* rays_o, const float* rays_d, 
   a.rays_o = rays_o; a.rays_d = rays_d; a.tvals = tvals; a.t_ray_stride = t_ray_stride;
   a.n_points = n_rays * n_samples; a.n_samples = n_samples; a.packed = (const float*)packed; a.raw = raw; a.save = save;
   a.density_only = density_only;
-  // stamp: 1 = the rows of density-free tiles are NOT stored (fp32 chain, for-compositing entry with the list available)
-  const bool rows_skipped = precision == NERF_PREC_F32 && !density_only && skip_dead;
+  // stamp: 1 = the rows of density-free tiles are NOT stored (for-compositing entry with the list available)
+  const bool rows_skipped = (precision == NERF_PREC_F32 || precision == NERF_PREC_F32X) && !density_only && skip_dead;
   if (hipMemsetAsync(save + TrainSave::off_stamp(a.n_points), rows_skipped ? 0x01 : 0x00, 4 * sizeof(float), (hipStream_t)stream) != hipSuccess)
     return fail(NERF_ERR_HIP, "%s", "nerf_mlp_forward_rays_save: memset failed");
   if (precision == NERF_PREC_F32X) {
     const long long n_tiles = (a.n_points + kXTilePts - 1) / kXTilePts;
     const unsigned blocks = (unsigned)(n_tiles < num_cus() ? n_tiles : num_cus());
-    hipLaunchKernelGGL((nerf_mlp_f32x_kernel<true, true>), dim3(blocks), dim3(kXThreads), 0, (hipStream_t)stream, a);
+    if (density_only) hipLaunchKernelGGL((nerf_mlp_f32x_kernel<true, true, true>), dim3(blocks), dim3(kXThreads), 0, (hipStream_t)stream, a);
+    else if (skip_dead) hipLaunchKernelGGL((nerf_mlp_f32x_kernel<true, true, false, true>), dim3(blocks), dim3(kXThreads), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((nerf_mlp_f32x_kernel<true, true>), dim3(blocks), dim3(kXThreads), 0, (hipStream_t)stream, a);
     return check_launch("nerf_mlp_f32x_kernel<save>");
   }
   if (precision != NERF_PREC_F32) return fail(NERF_ERR_UNSUPPORTED, "%s", "nerf_mlp_forward_rays_save: f32 or f32x only");
