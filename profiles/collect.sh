@@ -19,7 +19,7 @@ for P in ${PRECS-f32 f16 f32x}; do
   tail -1 $D/bench_trace.log | cut -c1-200
 done
 for P in ${TRAIN_PRECS-f32 f32x}; do
-  D=gpurun_out/prof_train_$P; mkdir -p $D
+  D=gpurun_out/prof_train_$P${TRAIN_TAG-}; mkdir -p $D      # TRAIN_TAG=_dense with NERF_DEAD_TILE_SKIP=0 in the environment: every tile computed
   A="--mode train --precision $P --no-dense-compare"
   rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 bench.py --steps 10 --warmup 2 $A > $D/bench_trace.log 2>&1
   rocprofv3 --pmc $SQ --output-format csv -d $D/pmc_sq -- python3 bench.py --steps 2 --warmup 0 $A > $D/bench_pmc_sq.log 2>&1
