@@ -25,8 +25,10 @@ extern "C" {
 
 /* Version 2 (round 3).  Contracts that changed since version 1 (entry names and signatures did not):
  *   - the TrainSave / TrainGrad buffers (nerf_train_save_floats / nerf_train_grad_floats) hold pad32(P) rows per region, with the
- *     fp32 chain's ReLU sign-bit blocks, the live-tile flags / list / count and a "rows skipped" stamp appended;
- *     nerf_mlp_backward(NERF_PREC_F32) takes its ReLU masks from those sign bits (written by the SAVE forwards only);
+ *     ReLU sign-bit blocks, the live-tile flags / list / count and a "rows skipped" stamp appended;
+ *     nerf_mlp_backward (both precisions) takes its ReLU masks from those sign bits (written by the SAVE forwards only);
+ *   - both precisions: the density entries skip the colour branch (its rows and sign bits are not stored / not read), and lanes
+ *     past the last point write the pad32 padding rows of every region;
  *   - with dead-tile skipping (default; NERF_DEAD_TILE_SKIP=0 in the environment disables it) the g_z rows of tiles whose incoming
  *     gradient is zero throughout are left unwritten in `gsave` (point mode zero-fills the g_zv region, which
  *     nerf_viewdirs_backward sums over);
@@ -134,9 +136,9 @@ int32_t nerf_mlp_forward_rays_save(const float* rays_o, const float* rays_d, con
  * parameter gradients (state_dict order, nn.Linear layouts; the caller zeroes them) and, if `g_t` [P]
  * is given, writes d loss / d t through the points (x = o + d t, positional encoding included) -- the
  * path by which the coarse network is trained.
- * NERF_PREC_F32 needs a `save` written by the NERF_PREC_F32 SAVE forward: its ReLU masks come from the sign-bit blocks
- * that forward appends behind the activation rows (nerf_train_save_floats covers them); NERF_PREC_F32X reads the rows
- * themselves and accepts a `save` of either forward.  Both `save` and `gsave` regions hold their rows padded to a
+ * The ReLU masks come from the sign-bit blocks the SAVE forwards append behind the activation rows (nerf_train_save_floats
+ * covers them; both precisions write the same layout, so a `save` of either forward is accepted as long as it was written by the
+ * matching entry: full / for-compositing / density).  Both `save` and `gsave` regions hold their rows padded to a
  * multiple of 32 points (offsets are derived from the padded count, see csrc/nerf_mlp_f32.hip.inc TrainSave). */
 int64_t nerf_train_grad_floats(int64_t n_points);
 /* Dead-tile skipping (n_points a multiple of 32; exact): a tile of 32 consecutive points whose `draw` rows are
@@ -154,12 +156,12 @@ int32_t nerf_mlp_backward(const float* rays_o, const float* rays_d, const float*
                           void* stream);
 
 /* nerf_mlp_forward_rays_save for a fine pass whose `raw` goes to nerf_composite and whose `draw` will come from
- * nerf_composite_backward (training.RenderFunction): NERF_PREC_F32 stops a 32-point tile without a single sigma > 0 after the
- * sigma head (rgb = 0 there, as nerf_mlp_forward_rays_for_compositing) and stores nothing past its h6 row.  CONTRACT: the `draw`
+ * nerf_composite_backward (training.RenderFunction): a 32-point tile without a single sigma > 0 stops after the sigma head
+ * (rgb = 0 there, as nerf_mlp_forward_rays_for_compositing) and stores nothing past its h6 row (NERF_PREC_F32) / its h7 row
+ * (NERF_PREC_F32X: no feature / views rows, no views bits).  CONTRACT: the `draw`
  * later given to nerf_mlp_backward with this `save` must be zero wherever sigma <= 0 -- nerf_composite_backward guarantees it --
  * so that the backward pass, which skips tiles with a zero incoming gradient, never reads those rows.  With
- * NERF_DEAD_TILE_SKIP=0 in the environment (or a point count that is not a multiple of 32, or NERF_PREC_F32X) this is
- * nerf_mlp_forward_rays_save. */
+ * NERF_DEAD_TILE_SKIP=0 in the environment (or a point count that is not a multiple of 32) this is nerf_mlp_forward_rays_save. */
 int32_t nerf_mlp_forward_rays_save_for_compositing(const float* rays_o, const float* rays_d, const float* tvals,
                                                    int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
                                                    const void* packed, float* raw, float* save, int32_t precision, void* stream);
@@ -167,10 +169,10 @@ int32_t nerf_mlp_forward_rays_save_for_compositing(const float* rays_o, const fl
 /* Density-only twins for the COARSE pass of a training step.  In the reference's step only the coarse sigma is ever used
  * (it places the fine samples; the coarse colour is never composited, volume_renderer.py:385-397), so
  * d loss / d raw_coarse has identically zero rgb columns and the gradients of rgb_linear, views_linears.0 and
- * feature_linear of the coarse sub-model are exactly zero.  With NERF_PREC_F32 these entries skip that branch: the forward
+ * feature_linear of the coarse sub-model are exactly zero.  These entries skip that branch (both precisions): the forward
  * stops after the sigma head (raw = (0, 0, 0, sigma); feature / views rows are not stored), the backward starts at
  * g_h7 = w_alpha * g_sigma and leaves the three colour gradients as zeroed by the caller.  `draw`'s rgb columns are not
- * read.  `save` from the density forward must go to the density backward.  NERF_PREC_F32X: same as the full calls. */
+ * read.  `save` from the density forward must go to the density backward. */
 int32_t nerf_mlp_forward_rays_save_density(const float* rays_o, const float* rays_d, const float* tvals,
                                            int64_t t_ray_stride, int64_t n_rays, int32_t n_samples,
                                            const void* packed, float* raw, float* save, int32_t precision, void* stream);
