@@ -458,7 +458,8 @@ def test_network_forward_is_differentiable(amd, oracle, synthetic_sd, model, pre
     assert p_hip.grad is not None and torch.isfinite(p_hip.grad).all()
 
 
-def test_density_only_pair_equals_full_pair_with_zero_colour_gradient(amd, net, synthetic_sd):
+@pytest.mark.parametrize("precision", ["f32", "f32x"])
+def test_density_only_pair_equals_full_pair_with_zero_colour_gradient(amd, net, synthetic_sd, precision):
     """The coarse pass of a training step runs nerf_mlp_forward_rays_save_density / nerf_mlp_backward_density (the colour
     branch is computed by the reference but never used: SURVEY F6/F10).  Against the full pair fed a d loss / d raw with
     zero rgb columns: sigma bit-identical, the 18 trunk / alpha gradients and d loss / d t equal to rounding (the
@@ -477,8 +478,10 @@ def test_density_only_pair_equals_full_pair_with_zero_colour_gradient(amd, net, 
     params = [p.detach().contiguous() for p in net.model.ordered_params()]
     arr = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in params])
     st = L.stream_of(o.device)
-    pk_b = torch.empty(int(lib.nerf_packed_bwd_bytes(0)), dtype=torch.uint8, device="cuda")
-    L.check(lib.nerf_pack_model_bwd(arr, pk_b.data_ptr(), 0, st))
+    prec = L.PRECISIONS[precision]                           # (f32x: both instances since round 3)
+    net.precision = precision
+    pk_b = torch.empty(int(lib.nerf_packed_bwd_bytes(prec)), dtype=torch.uint8, device="cuda")
+    L.check(lib.nerf_pack_model_bwd(arr, pk_b.data_ptr(), prec, st))
     P = n * S
     out = {}
     for tag, fwd, bwd in (("full", lib.nerf_mlp_forward_rays_save, lib.nerf_mlp_backward),
@@ -488,9 +491,9 @@ def test_density_only_pair_equals_full_pair_with_zero_colour_gradient(amd, net, 
         gsave = torch.empty(int(lib.nerf_train_grad_floats(P)), device="cuda")
         g_t = torch.empty(n, S, device="cuda")
         grads = [torch.zeros_like(p) for p in params]
-        L.check(fwd(L.ptr(o), L.ptr(d), L.ptr(t_c), 0, n, S, net.packed("").data_ptr(), L.ptr(raw), L.ptr(save), 0, st))
+        L.check(fwd(L.ptr(o), L.ptr(d), L.ptr(t_c), 0, n, S, net.packed("").data_ptr(), L.ptr(raw), L.ptr(save), prec, st))
         L.check(bwd(L.ptr(o), L.ptr(d), L.ptr(t_c), 0, n, S, pk_b.data_ptr(), L.ptr(G), L.ptr(save), L.ptr(gsave), L.ptr(g_t),
-                    _grad_ptrs(amd, grads), 0, st))
+                    _grad_ptrs(amd, grads), prec, st))
         torch.cuda.synchronize()
         out[tag] = (raw, g_t, grads)
     assert torch.equal(out["full"][0][..., 3], out["density"][0][..., 3])
@@ -502,6 +505,7 @@ def test_density_only_pair_equals_full_pair_with_zero_colour_gradient(amd, net, 
             assert torch.all(gf == 0) and torch.all(gd == 0), name
         else:
             assert gf.abs().max() > 0 and _rel(gd, gf.cpu()) <= 2e-6, name
+    net.precision = "f32"
 
 
 @pytest.mark.parametrize("shape", [(48, 192), (1, 32), (7, 160)])       # 288 tiles; a single tile; 35 tiles (fewer than scan threads)
