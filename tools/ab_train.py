@@ -2,6 +2,7 @@
 """Interleaved in-process A/B timing of build variants of the TRAINING kernels (companion of tools/ab_bench.py).
 
     python tools/ab_train.py f32 "base:" "nosave:-DNERF_F32_HACK_NOSAVE=1" "nomask:-DNERF_BWD_HACK_NOMASK=1" ...
+    python tools/ab_train.py f32x "base:" "nostore:-DNERF_F32X_HACK_SAVE_NOSTORE=1 -DNERF_XB_HACK_NOSTORE=1" "direct:-DNERF_F32X_STAGE_TRUNK=0 -DNERF_F32X_STAGE_DENS=0"
 
 Per variant and round: nerf_mlp_forward_rays_save (fine model, 4096 x 192 points) and nerf_mlp_backward (data-gradient
 chain + all weight-gradient launches) on the same inputs, HIP events around each call.  Developer tool."""

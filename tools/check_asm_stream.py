@@ -136,7 +136,9 @@ def main():
             print("   ", kind, "|", ld, "|", use)
         bad += len(hz)
         if n == 0:
-            print("    (no asm loads found: NERF_F32_ASM_LOADS off?)")
+            # the training (SAVE) instances of nerf_mlp_f32x_kernel read LDS with compiler-scheduled loads on purpose
+            save_f32x = k.startswith("_Z20nerf_mlp_f32x_kernelI") and re.match(r"_Z20nerf_mlp_f32x_kernelILb[01]ELb1E", k)
+            print("    (compiler-scheduled instance: nothing to check)" if save_f32x else "    (no asm loads found: NERF_F32_ASM_LOADS off?)")
     return 1 if bad else 0
 
 
