@@ -23,7 +23,7 @@
 // library that passes nerf_abi_version() and computes garbage.
 #define NERF_ANY_TIMING_HACK (NERF_F32_HACK_NOLOAD || NERF_F32_HACK_NOBIAS || NERF_F32_HACK_NORELU || NERF_F32_HACK_NOPE || \
                               0 || NERF_F32_ASM_OVERRUN || NERF_F32_HACK_NOSAVE || NERF_BWD_HACK_NOMASK || 0 || NERF_F16_HACK_NOADV || NERF_F16_HACK_NOBARRIER || NERF_WG_HACK_NOATOMIC || NERF_F16_HACK_NOEPI || 0 || NERF_F16_HACK_NORELU || NERF_F32X_HACK_NOADV || \
-                              NERF_F32X_HACK_NOPE || NERF_F32X_HACK_NOEPI)
+                              NERF_F32X_HACK_NOPE || NERF_F32X_HACK_NOEPI || NERF_F32X_HACK_SAVE_NOSTORE || NERF_XB_HACK_NOSTORE)
 // (two structural knobs of the SAVE forward also break results when switched off: no rows / no sign bits stored)
 #if (NERF_ANY_TIMING_HACK || NERF_SAVE_TAPS == 0 || 2 == 0) && !defined(NERF_TIMING_BUILD)
 #error "a NERF_*_HACK_* / NERF_F32_ASM_OVERRUN timing switch is set: such a library computes wrong results; build it with -DNERF_TIMING_BUILD (tools/ab_bench.py does) so that nerf_build_flags() reports it"
