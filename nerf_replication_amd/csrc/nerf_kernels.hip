@@ -16,6 +16,9 @@
 #include "nerf_mlp_bwd_f32.hip.inc"
 #include "nerf_mlp_bwd_f32x.hip.inc"
 #include "nerf_wgrad_bf16x3.hip.inc"
+// the split-fp16 MLP kernels are compiled in a unit of their own (nerf_kernels_x.hip says why); here they are only launched
+#define NERF_X_INST extern template
+#include "nerf_kernels_x.inst.inc"
 
 // Timing-only switches (tools/ab_bench.py) change the NUMERICS of the kernels they are compiled into.  A library
 // built with any of them set must say so: it only compiles with -DNERF_TIMING_BUILD, and then reports it through

@@ -19,13 +19,24 @@ sys.path.insert(0, REPO)
 CSRC = os.path.join(REPO, "nerf_replication_amd", "csrc")
 VDIR = os.path.join(CSRC, "variants")
 FLAGS = "-O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -shared -fPIC -DNERF_TIMING_BUILD"
+XFLAGS = "-mllvm -amdgpu-mfma-vgpr-form=1"        # csrc/Makefile: what nerf_kernels_x.hip is compiled with on top
 
 
 def build(name, extra):
     os.makedirs(VDIR, exist_ok=True)
     out = os.path.join(VDIR, f"lib_{name}.so")
-    cmd = f"/opt/rocm/bin/hipcc {FLAGS} {extra} -o {out} {os.path.join(CSRC, 'nerf_kernels.hip')}"
-    subprocess.run(cmd, shell=True, check=True)
+    # two translation units, as csrc/Makefile builds them (the split-fp16 kernels with XFLAGS on top)
+    objs = []
+    procs = []
+    for unit, x in (("nerf_kernels", ""), ("nerf_kernels_x", XFLAGS)):
+        obj = os.path.join(VDIR, f"{unit}_{name}.o")
+        objs.append(obj)
+        procs.append(subprocess.Popen(f"/opt/rocm/bin/hipcc {FLAGS.replace('-shared ', '')} {x} {extra} -c -o {obj} {os.path.join(CSRC, unit + '.hip')}", shell=True))
+    if any(pr.wait() != 0 for pr in procs):
+        raise SystemExit(f"variant {name!r}: compile failed")
+    subprocess.run(f"/opt/rocm/bin/hipcc {FLAGS} -o {out} {' '.join(objs)}", shell=True, check=True)
+    for o in objs:
+        os.remove(o)
     with open(out + ".flags", "w") as f:          # what this binary was built with: a stale or flag-less rebuild cannot pose as it
         f.write(extra.strip())
     if os.environ.get("AB_NO_CHECK") != "1":      # a variant whose asm rings the compiler broke measures (and computes) nonsense

@@ -18,7 +18,6 @@ import sys
 import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(REPO, "nerf_replication_amd", "csrc", "nerf_kernels.hip")
 # code-generation flags: the Makefile passes ITS OWN ($(CXXFLAGS)) through --flags, so the ISA checked here is the ISA
 # of the library being built; the default below mirrors csrc/Makefile for stand-alone runs
 FLAGS = "-O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950"
@@ -31,6 +30,12 @@ KERNELS = ["_Z19nerf_mlp_f32_kernelILb1ELb0ELb0ELb0EEv7MlpArgs", "_Z19nerf_mlp_f
            "_Z28nerf_wgrad256_f32_asm_kernelILb0EEv10WgradBatch", "_Z28nerf_wgrad256_f32_asm_kernelILb1EEv10WgradBatch"]
 # every instance of these templates found in the ISA is checked too (their ring depth is part of the mangled name)
 KERNEL_PREFIXES = ["_Z29nerf_wgrad_vec_f32_asm_kernelI", "_Z20nerf_mlp_f32x_kernelI"]
+# The library is two translation units (csrc/Makefile): the split-fp16 kernels are compiled with XFLAGS on top of the common
+# flags (nerf_kernels_x.hip says why); each unit is checked on the flags IT is built with.
+XFLAGS = "-mllvm -amdgpu-mfma-vgpr-form=1"
+CSRC = os.path.join(REPO, "nerf_replication_amd", "csrc")
+UNITS = [{"src": os.path.join(CSRC, "nerf_kernels.hip"), "x": False, "kernels": KERNELS, "prefixes": ["_Z29nerf_wgrad_vec_f32_asm_kernelI"]},
+         {"src": os.path.join(CSRC, "nerf_kernels_x.hip"), "x": True, "kernels": [], "prefixes": ["_Z20nerf_mlp_f32x_kernelI"]}]
 
 
 def vregs(text):
@@ -115,30 +120,36 @@ def main():
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("--flags", default=FLAGS, help="code-generation flags of the build being checked (csrc/Makefile: $(CXXFLAGS))")
+    ap.add_argument("--xflags", default=XFLAGS, help="what the split-fp16 unit is compiled with on top of --flags (csrc/Makefile: $(XFLAGS))")
     ap.add_argument("--hipcc", default=HIPCC)
     args = ap.parse_args()
-    with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "k.s")
-        extra = os.environ.get("NERF_CHECK_EXTRA_FLAGS", "")     # e.g. -DNERF_F32_ASM_OVERRUN=1 -DNERF_TIMING_BUILD: must report hazards
-        subprocess.run(f"{args.hipcc} {args.flags} -S --cuda-device-only {extra} -o {out} {SRC}", shell=True, check=True,
-                       stderr=subprocess.DEVNULL)
-        lines = open(out).read().split("\n")
+    extra = os.environ.get("NERF_CHECK_EXTRA_FLAGS", "")     # e.g. -DNERF_F32_ASM_OVERRUN=1 -DNERF_TIMING_BUILD: must report hazards
     bad = 0
-    found = sorted({m.group(1) for l in lines for m in [re.match(r"^(_Z\w+):", l)] if m and m.group(1).startswith(tuple(KERNEL_PREFIXES))})
-    for pre in KERNEL_PREFIXES:
-        if not any(k.startswith(pre) for k in found):
-            print("    (no instance of", pre, "found)")
-            bad += 1
-    for k in KERNELS + found:
-        n, hz = check(lines, k)
-        print(f"{k}: {n} asm loads, {len(hz)} hazards")
-        for kind, ld, use in hz[:10]:
-            print("   ", kind, "|", ld, "|", use)
-        bad += len(hz)
-        if n == 0:
-            # the training (SAVE) instances of nerf_mlp_f32x_kernel read LDS with compiler-scheduled loads on purpose
-            save_f32x = k.startswith("_Z20nerf_mlp_f32x_kernelI") and re.match(r"_Z20nerf_mlp_f32x_kernelILb[01]ELb1E", k)
-            print("    (compiler-scheduled instance: nothing to check)" if save_f32x else "    (no asm loads found: NERF_F32_ASM_LOADS off?)")
+    with tempfile.TemporaryDirectory() as d:
+        procs = []
+        for i, u in enumerate(UNITS):                          # both units compile side by side
+            out = os.path.join(d, f"k{i}.s")
+            cmd = f"{args.hipcc} {args.flags} {args.xflags if u['x'] else ''} -S --cuda-device-only {extra} -o {out} {u['src']}"
+            procs.append((u, out, subprocess.Popen(cmd, shell=True, stderr=subprocess.DEVNULL)))
+        for u, out, pr in procs:
+            if pr.wait() != 0:
+                raise SystemExit(f"compiling {u['src']} failed")
+            lines = open(out).read().split("\n")
+            found = sorted({m.group(1) for l in lines for m in [re.match(r"^(_Z\w+):", l)] if m and m.group(1).startswith(tuple(u["prefixes"]))})
+            for pre in u["prefixes"]:
+                if not any(k.startswith(pre) for k in found):
+                    print("    (no instance of", pre, "found)")
+                    bad += 1
+            for k in u["kernels"] + found:
+                n, hz = check(lines, k)
+                print(f"{k}: {n} asm loads, {len(hz)} hazards")
+                for kind, ld, use in hz[:10]:
+                    print("   ", kind, "|", ld, "|", use)
+                bad += len(hz)
+                if n == 0:
+                    # the training (SAVE) instances of nerf_mlp_f32x_kernel read LDS with compiler-scheduled loads on purpose
+                    save_f32x = k.startswith("_Z20nerf_mlp_f32x_kernelI") and re.match(r"_Z20nerf_mlp_f32x_kernelILb[01]ELb1E", k)
+                    print("    (compiler-scheduled instance: nothing to check)" if save_f32x else "    (no asm loads found: NERF_F32_ASM_LOADS off?)")
     return 1 if bad else 0
 
 
